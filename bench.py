@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X linear-response sensitivity hot path.
+
+Workload (BASELINE.json configs[1]): weighted logistic regression, N = 1,000,000 rows,
+D = 100, fp64, ridge prior 1: one "step" = all-N infinitesimal-jackknife sensitivities
+d theta-hat / d w  from device-resident (X, y, w, theta-hat) to device-resident S:
+    fused link+gradient+Hessian SYRK  ->  (all-reduce of H when row-sharded)
+    -> Cholesky -> TRSM operand pack -> MFMA multi-RHS TRSM  S = -H^{-1} (diag(r) X)^T
+Metric: IJ sensitivities / second = (rows over all ranks) / (max-over-ranks step time).
+With --gpus N > 1 every rank holds its own N-row shard (weak scaling); the only
+collective is the RCCL all-reduce of the D x D partial Hessian.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X vendor FP64 matrix peak
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--rows", type=int, default=1_000_000, help="rows per GPU")
+    p.add_argument("--dim", type=int, default=100)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-rows", type=int, default=1_000_000)
+    return p.parse_args()
+
+
+def cpu_baseline(Xh, yh, wh, theta_h, prior, S_dev_rows, n_sample):
+    """Time the oracle (CPU restatement: NumPy Hessian + the reference's LAPACK calls
+    cho_factor/cho_solve with nrhs = N) on a bounded sample of the same workload and
+    use it as the parity checker for the GPU result."""
+    from oracle import glm
+    import threadpoolctl
+    n = min(n_sample, Xh.shape[0])
+    Xs, ys, ws = Xh[:n], yh[:n], wh[:n]
+    glm.sensitivity("logistic", Xs[:20000], ys[:20000], theta_h, ws[:20000], prior=prior)   # warm-up
+    t0 = time.perf_counter()
+    H, jac0, S = glm.sensitivity("logistic", Xs, ys, theta_h, ws, prior=prior)
+    dt = time.perf_counter() - t0
+    threads = 1
+    try:
+        infos = threadpoolctl.threadpool_info()
+        threads = max([i.get("num_threads", 1) for i in infos if i.get("user_api") == "blas"] or [1])
+    except Exception:
+        pass
+    return dict(value=n / dt, unit="sensitivities/s", cores=int(threads), kind="port",
+                sample="oracle.glm.sensitivity (NumPy X^T D X + scipy cho_factor/cho_solve, nrhs=N) on the first "
+                       "%d rows of the same N x D workload, %.2f s" % (n, dt)), H, S
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        group = dist.group.WORLD
+
+    import vittles_amd as va
+    from vittles_amd.linalg import DeviceCholesky
+    from vittles_amd import _lib, device as dev
+
+    N, D = args.rows, args.dim
+    prior = 1.0
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    X = torch.randn((N, D), dtype=torch.float64, device=device, generator=gen)
+    gth = torch.Generator(device=device)
+    gth.manual_seed(99)   # same theta* on every rank
+    theta_star = torch.randn(D, dtype=torch.float64, device=device, generator=gth) / D ** 0.5
+    y = (torch.rand(N, dtype=torch.float64, device=device, generator=gen) < torch.sigmoid(X @ theta_star)).double()
+    w = torch.ones(N, dtype=torch.float64, device=device)
+    obj = va.WeightedGLMObjective(X, y, family="logistic", prior=prior, process_group=group)
+
+    # theta-hat: Newton steps with the same kernels (set-up, untimed).
+    theta = torch.zeros(D, dtype=torch.float64, device=device)
+    for _ in range(12):
+        out = obj.fused(theta.clone(), w)
+        step = DeviceCholesky.factor(out["H"]).solve(out["g"])
+        theta = theta - step
+        if float(step.norm()) < 1e-12 * max(1.0, float(theta.norm())):
+            break
+    grad_norm = float(obj.fused(theta.clone(), w)["g"].norm())
+
+    lib = _lib.load()
+    S = torch.empty((N, D), dtype=torch.float64, device=device)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+           torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def step(i=None):
+        obj._cache_key = None               # no cached pass: every step streams X
+        if i is not None:
+            ev[i][0].record()
+        out = obj.fused(theta, w)           # K0+K1+K3 (+ all-reduce)
+        if i is not None:
+            ev[i][1].record()
+        chol = DeviceCholesky.factor(out["H"], check=False)   # K4; info checked after the solve is queued
+        chol.pack()
+        if i is not None:
+            ev[i][2].record()
+        chol.solve_rows(X, rowscale=out["r"], alpha=-1.0, out=S)   # K2+K5
+        if i is not None:
+            ev[i][3].record()
+        chol.raise_if_failed()              # host reads potrf's info (the step's only sync)
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    ms_hess = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    ms_chol = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    ms_trsm = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * N / (dt / args.steps)
+        # dominant kernel: the MFMA TRSM (algorithmic flops 2 D^2 N, bytes 16 N D + 8 N)
+        trsm_flops = 2.0 * D * D * N
+        trsm_tflops = trsm_flops / (ms_trsm * 1e-3) / 1e12
+        syrk_flops = float(N) * D * (D + 1)
+        result = {
+            "metric": "IJ sensitivities/sec (all-N dtheta/dw) at N=1M,D=100",
+            "value": value, "unit": "sensitivities/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "weighted logistic regression N=%d D=%d fp64 per GPU "
+                                   "(Hessian SYRK + multi-RHS TRSM), ridge prior 1" % (N, D),
+                       "rows_per_gpu": N, "dim": D, "parallelism": "row-sharded dp%d" % world,
+                       "grad_norm_at_theta_hat": grad_norm},
+            "roofline": {"bound": "mfma", "kernel": "k_trsm_rows_small (K2+K5 sens TRSM)",
+                         "achieved": trsm_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": trsm_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "ms": ms_trsm,
+                         "hbm_GBs": (16.0 * N * D + 8.0 * N) / (ms_trsm * 1e-3) / 1e9},
+            "stages_ms": {"fused_link_grad_hessian": ms_hess, "cholesky_pack": ms_chol, "sens_trsm": ms_trsm},
+            "syrk": {"TFLOPs_triangle": syrk_flops / (ms_hess * 1e-3) / 1e12,
+                     "TFLOPs_full_square": 2.0 * N * D * D / (ms_hess * 1e-3) / 1e12,
+                     "hbm_GBs": (8.0 * N * D + 24.0 * N) / (ms_hess * 1e-3) / 1e9},
+        }
+        if not args.no_cpu_baseline:
+            n_s = min(args.cpu_rows, N)
+            Xh = X[:n_s].cpu().numpy()
+            yh = y[:n_s].cpu().numpy()
+            wh = w[:n_s].cpu().numpy()
+            theta_h = theta.cpu().numpy()
+            base, H_cpu, S_cpu = cpu_baseline(Xh, yh, wh, theta_h, prior, None, n_s)
+            result["cpu_baseline"] = base
+            if n_s == N and world == 1:
+                # same rows on both sides -> full parity check of H and S
+                Hg = out["H"].cpu().numpy()
+                Sg = S.cpu().numpy()
+                result["parity"] = {
+                    "H_max_rel_err": float(np.abs(Hg - H_cpu).max() / np.abs(H_cpu).max()),
+                    "S_max_rel_err": float(np.abs(Sg.T - S_cpu).max() / np.abs(S_cpu).max()),
+                    "rows_checked": int(N), "tolerance": 1e-10}
+            result["speedup_vs_cpu_baseline"] = value / base["value"]
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+/* vittles_hip.h -- C-ABI of the MI355X (gfx950) linear-response sensitivity hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / C++ types.
+ * Every pointer named *_dev is a DEVICE pointer (hipMalloc'd or owned by a torch
+ * tensor); the library never allocates or frees device memory -- scratch comes in
+ * through a `ws` pointer whose size the matching *_workspace_bytes() query states.
+ * All kernels are enqueued on the `stream` argument (a hipStream_t passed as void*;
+ * NULL = the default stream) and return without synchronising.
+ *
+ * Return value: 0 = ok; <0 = argument / HIP error (vt_error_string() names it);
+ * LAPACK-style `info` values (k>0: leading minor k not positive definite) are
+ * written to an `int* info_dev` on the device so that no call forces a host sync.
+ *
+ * Each entry point cites the interface of the reference (rgiordan/vittles, paths
+ * relative to /root/reference) that it replaces.  The reference has no native
+ * code at all: what is replaced is the work that autograd / SciPy perform inside
+ * the cited Python lines.
+ *
+ * Conventions
+ *   X        : (N, D) row-major fp64, leading dimension ldx (elements, >= D).
+ *   theta    : (D,) fp64.   y, w, offset : (N,) fp64 (offset may be NULL).
+ *   objective: f(theta, w) = scale * sum_n w_n ell(x_n.theta + offset_n, y_n)
+ *                            + 0.5 * sum_j prior_j theta_j^2
+ *   family   : VT_FAMILY_LOGISTIC  ell = log(1+e^z) - y z
+ *              VT_FAMILY_POISSON   ell = e^z - y z
+ *              VT_FAMILY_GAUSSIAN  ell = (z - y)^2 / 2
+ *   r_n = scale * ell'(z_n)          (cross-Hessian column n is r_n * x_n)
+ *   d_n = scale * w_n * ell''(z_n)   (Hessian row weight)
+ *   H   : (D, D) row-major, FULL symmetric storage, leading dimension ldh.
+ *   L   : lower Cholesky factor, H = L L^T, row-major in the lower triangle
+ *         (== the transpose of scipy.linalg.cho_factor's default upper factor).
+ *   S   : (N, D) row-major, row n = d theta-hat / d w_n.  Viewed transposed this
+ *         is the reference's (D, N) `_sens_mat`, F-contiguous exactly as
+ *         scipy.linalg.cho_solve returns it.
+ */
+#ifndef VITTLES_HIP_H
+#define VITTLES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VT_OK                  0
+#define VT_ERR_BAD_ARG        -1
+#define VT_ERR_UNSUPPORTED    -2   /* shape outside what the kernels cover */
+#define VT_ERR_WORKSPACE      -3   /* ws_bytes too small */
+#define VT_ERR_HIP            -4   /* a HIP runtime call failed */
+#define VT_ERR_NO_DEVICE      -5
+
+#define VT_FAMILY_LOGISTIC 0
+#define VT_FAMILY_POISSON  1
+#define VT_FAMILY_GAUSSIAN 2
+
+/* Largest D handled by the register/LDS-resident ("small-D") SYRK / Cholesky /
+ * TRSM kernels.  Larger D takes the tiled kernels. */
+#define VT_SMALL_D_MAX 128
+
+int         vt_version(void);
+const char* vt_error_string(int code);
+/* Number of visible HIP devices (<0 on error).  Product code calls this to fail
+ * loudly when no GPU is present. */
+int         vt_device_count(void);
+
+/* ---- K0 + K1 + K3 fused: link, gradient and Hessian in ONE pass over X --------
+ * Replaces: autograd.hessian(objective_fun, argnum=0)(theta, w)
+ *             vittles/sensitivity_lib.py:381-383  (also lr_cov_lib.py:101-102)
+ *           autograd.grad(objective_fun, argnum=0)(theta, w)
+ *             vittles/sensitivity_lib.py:354, 203-209
+ *           and the per-row factors of the cross-Hessian
+ *             vittles/sensitivity_lib.py:180-181, 217-219
+ * H_dev (D,D) <- X^T diag(d) X (+ diag(prior) if prior_dev != NULL)
+ * g_dev (D,)  <- X^T (w .* r)  (+ prior .* theta if prior_dev != NULL)   [may be NULL]
+ * r_dev, d_dev (N,) per-row factors                                     [may be NULL]
+ * Row-sharded use: every rank calls this on its rows; only one rank passes prior. */
+size_t vt_glm_hessian_workspace_bytes(int64_t N, int D);
+int    vt_glm_hessian(int family, const double* X_dev, int64_t ldx,
+                      const double* theta_dev, const double* y_dev, const double* w_dev,
+                      const double* offset_dev, double scale, const double* prior_dev,
+                      int64_t N, int D,
+                      double* H_dev, int ldh, double* g_dev, double* r_dev, double* d_dev,
+                      void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ---- K4: dense Cholesky -------------------------------------------------------
+ * Replaces: scipy.linalg.cho_factor(h)          vittles/solver_lib.py:26-27
+ * In place on the lower triangle of the row-major A (strict upper part untouched).
+ * *info_dev <- 0, or k>0 if the leading minor of order k is not positive definite
+ * (LAPACK dpotrf's info, which SciPy turns into LinAlgError). */
+size_t vt_potrf_workspace_bytes(int D);
+int    vt_potrf(double* A_dev, int lda, int D, int* info_dev,
+                void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ---- K5 (generic): solve with an arbitrary-stride right-hand side ----------------
+ * Replaces: scipy.linalg.cho_solve(h_chol, v)   vittles/solver_lib.py:28-29
+ * B(i,k) lives at B_dev[i*ldb_row + k*ldb_col], i<D, k<nrhs; solved in place. */
+int    vt_potrs(const double* L_dev, int ldl, int D,
+                double* B_dev, int64_t ldb_row, int64_t ldb_col, int64_t nrhs, void* stream);
+
+/* ---- K5 (MFMA TRSM): operand pack + row-major multi-RHS solve ---------------------
+ * vt_trsm_pack turns L into the MFMA A-operand images (inverted 16x16 diagonal
+ * blocks folded into the off-diagonal blocks) the TRSM kernel keeps in LDS. */
+size_t vt_trsm_pack_bytes(int D);
+int    vt_trsm_pack(const double* L_dev, int ldl, int D, void* pack_dev, void* stream);
+
+/* Out[n,:] = alpha * s_n * H^{-1} B[n,:]   for n < N  (s_n = 1 if rowscale_dev NULL)
+ * Replaces: `-1 * self._hess_solver(self._estimating_equation_jac0)`
+ *             vittles/sensitivity_lib.py:226  (dpotrs with nrhs = N)
+ * With B = X, rowscale = r, alpha = -1 this is K2+K5 fused: the (D,N) cross-Hessian
+ * (sensitivity_lib.py:217-219) is never materialised. */
+int    vt_trsm_rows(const void* pack_dev, int D,
+                    const double* B_dev, int64_t ldb, const double* rowscale_dev, double alpha,
+                    int64_t N, double* Out_dev, int64_t ldo, void* stream);
+
+/* ---- Row-streaming kernels (HBM-bound; X read once) ------------------------------
+ * All take a workspace of vt_rows_workspace_bytes(D) bytes. */
+size_t vt_rows_workspace_bytes(int D);
+
+/* K0: z_n = x_n.theta + offset_n, r_n, d_n (any of the three outputs may be NULL).
+ * Replaces the forward pass autograd traces inside objective_fun
+ *   (vittles/sensitivity_lib.py:354-383 evaluate it once per derivative sweep). */
+int    vt_glm_link(int family, const double* X_dev, int64_t ldx, const double* theta_dev,
+                   const double* y_dev, const double* w_dev, const double* offset_dev, double scale,
+                   int64_t N, int D, double* z_dev, double* r_dev, double* d_dev,
+                   void* ws_dev, size_t ws_bytes, void* stream);
+
+/* K3: g = X^T (w .* r) (+ prior .* theta).
+ * Replaces: autograd.grad(objective_fun, argnum=0)(theta, w)
+ *             vittles/sensitivity_lib.py:354, 203-209; vittles/lr_cov_lib.py:110 */
+int    vt_glm_grad(int family, const double* X_dev, int64_t ldx, const double* theta_dev,
+                   const double* y_dev, const double* w_dev, const double* offset_dev, double scale,
+                   const double* prior_dev, int64_t N, int D, double* g_dev, double* r_dev, double* d_dev,
+                   void* ws_dev, size_t ws_bytes, void* stream);
+
+/* K6: fused Hessian-vector product  out = X^T (d .* (X v)) + prior .* v
+ * (prior_dev (D,) if non-NULL, else the scalar prior_scalar).
+ * Replaces: the `mat_times_vec` callable a user hands to get_cg_solver
+ *             vittles/solver_lib.py:70-98 (autograd.hessian_vector_product,
+ *             vittles/lr_cov_lib.py:79-80), one call per CG iteration. */
+int    vt_glm_hvp(const double* X_dev, int64_t ldx, const double* d_dev, const double* prior_dev,
+                  double prior_scalar, const double* v_dev, int64_t N, int D, double* out_dev,
+                  void* ws_dev, size_t ws_bytes, void* stream);
+
+/* K9: out (D,) = A^T u for a row-major (N, D) A.
+ * Replaces: `self._sens_mat @ (new_hyper_par_value - self._hyper_val0)`
+ *             vittles/sensitivity_lib.py:245-247 (A = S stored (N, D), u = delta w). */
+int    vt_gemv_t(const double* A_dev, int64_t lda, const double* u_dev, int64_t N, int D,
+                 double* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* out (N,) = A v for a row-major (N, D) A (moment Jacobians times a vector, K8). */
+int    vt_gemv(const double* A_dev, int64_t lda, const double* v_dev, int64_t N, int D,
+               double* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* value_dev[0] = scale * sum_n w_n ell(z_n, y_n)  (the caller adds the prior term).
+ * Replaces: evaluating objective_fun(theta, w) itself (vittles/sensitivity_lib.py:303-320). */
+int    vt_glm_value(int family, const double* X_dev, int64_t ldx, const double* theta_dev,
+                    const double* y_dev, const double* w_dev, const double* offset_dev, double scale,
+                    int64_t N, int D, double* value_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITTLES_HIP_H */

@@ -1,0 +1,460 @@
+// K4 / K5: dense Cholesky, generic triangular solve, and the MFMA multi-RHS TRSM.
+// Replaces scipy.linalg.cho_factor / cho_solve as the reference calls them
+// (vittles/solver_lib.py:26-29) and the N-right-hand-side solve behind
+// `-1 * self._hess_solver(jac0)` (vittles/sensitivity_lib.py:226).
+#include "vt_common.h"
+
+namespace {
+
+constexpr int kSmallLd = VT_SMALL_D_MAX + 1;  // odd stride: column walks are bank-conflict free
+
+// ------------------------------------------------------------------ potrf -------
+// One workgroup, matrix resident in LDS (D <= 128: 132 KB of the CU's 160 KB).
+// Right-looking column Cholesky; latency-bound by construction (D^3/3 flops is
+// nothing), so the budget is barriers: 2 per column.
+__global__ __launch_bounds__(512) void k_potrf_small(double* A, int lda, int D, int* info) {
+    __shared__ double a[VT_SMALL_D_MAX * kSmallLd];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < D * D; idx += 512) {
+        int i = idx / D, j = idx - i * D;
+        if (j <= i) a[i * kSmallLd + j] = A[(int64_t)i * lda + j];
+    }
+    __syncthreads();
+    int bad = 0;
+    for (int k = 0; k < D; ++k) {
+        double akk = a[k * kSmallLd + k];
+        if (!(akk > 0.0)) {  // also catches NaN, as LAPACK's disnan test does
+            bad = k + 1;
+            break;
+        }
+        double piv = sqrt(akk);
+        double rpiv = 1.0 / piv;
+        __syncthreads();  // everyone has read a[k][k]
+        for (int i = k + 1 + tid; i < D; i += 512) a[i * kSmallLd + k] *= rpiv;
+        if (tid == 0) a[k * kSmallLd + k] = piv;
+        __syncthreads();
+        for (int i = k + 1 + (tid >> 5); i < D; i += 16) {
+            double aik = a[i * kSmallLd + k];
+            for (int j = k + 1 + (tid & 31); j <= i; j += 32)
+                a[i * kSmallLd + j] -= aik * a[j * kSmallLd + k];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int idx = tid; idx < D * D; idx += 512) {
+        int i = idx / D, j = idx - i * D;
+        if (j <= i) A[(int64_t)i * lda + j] = a[i * kSmallLd + j];
+    }
+    if (tid == 0) *info = bad;
+}
+
+// ------------------------------------------------------------------ potrs -------
+// Generic (any strides, any D that fits LDS): one wave per right-hand side, the
+// solution vector lives in LDS, the 64 lanes split each row's dot product.
+__global__ __launch_bounds__(64) void k_potrs_generic(const double* L, int ldl, int D, double* B,
+                                                      int64_t ldr, int64_t ldc, int64_t nrhs) {
+    extern __shared__ double x[];
+    const int lane = threadIdx.x;
+    for (int64_t k = blockIdx.x; k < nrhs; k += gridDim.x) {
+        double* b = B + k * ldc;
+        for (int i = lane; i < D; i += 64) x[i] = b[(int64_t)i * ldr];
+        __syncthreads();
+        for (int i = 0; i < D; ++i) {  // L y = b
+            const double* Li = L + (int64_t)i * ldl;
+            double p = 0.0;
+            for (int j = lane; j < i; j += 64) p = fma(Li[j], x[j], p);
+            p = vt_sum64(p);
+            __syncthreads();
+            if (lane == 0) x[i] = (x[i] - p) / Li[i];
+            __syncthreads();
+        }
+        for (int i = D - 1; i >= 0; --i) {  // L^T z = y
+            double p = 0.0;
+            for (int j = i + 1 + lane; j < D; j += 64) p = fma(L[(int64_t)j * ldl + i], x[j], p);
+            p = vt_sum64(p);
+            __syncthreads();
+            if (lane == 0) x[i] = (x[i] - p) / L[(int64_t)i * ldl + i];
+            __syncthreads();
+        }
+        for (int i = lane; i < D; i += 64) b[(int64_t)i * ldr] = x[i];
+        __syncthreads();
+    }
+}
+
+// -------------------------------------------------------------- TRSM pack -------
+// Logical -> hardware index maps inside a 16-wide block.  A "permuted" (full)
+// block keeps logical index 4q+s at accumulator register s of lane group q, so a
+// lane owns 4 CONSECUTIVE columns (32 contiguous bytes of a row of X / S); the
+// trailing partial block keeps the native MFMA order 4s+q so that its all-zero
+// k-steps can be skipped.
+__host__ __device__ __forceinline__ int vt_perm(bool permuted, int p) {
+    return permuted ? (4 * (p & 3) + (p >> 2)) : p;
+}
+
+// pack[(PI*4 + s)*64 + lane]: A operand of k-step s for block pair PI.
+//   forward  pair (j,i), i<=j : PI = tri(j,i)        F_jj = Linv_jj,  F_ji = -Linv_jj L_ji
+//   backward pair (j,i), i>=j : PI = NBT + tri(i,j)  B_jj = Linv_jj^T, B_ji = -Linv_jj^T L_ij^T
+// so that   Y_j = sum_{i<=j} F_ji (G_i | Y_i)   and   Z_j = B_jj Y_j + sum_{i>j} B_ji Z_i
+// are pure MFMA accumulations (no divisions, no subtractions in the solve kernel).
+__global__ __launch_bounds__(256) void k_trsm_pack(const double* L, int ldl, int D, double* pack) {
+    __shared__ double l[VT_SMALL_D_MAX * kSmallLd];
+    __shared__ double linv[8 * 16 * 17];
+    const int tid = threadIdx.x;
+    const int NB = (D + 15) >> 4, NP = NB * 16, NBT = NB * (NB + 1) / 2;
+    const bool lastperm = (D & 15) == 0;
+    for (int idx = tid; idx < NP * NP; idx += 256) {
+        int i = idx / NP, j = idx - i * NP;
+        double v = 0.0;
+        if (i < D && j <= i) v = L[(int64_t)i * ldl + j];
+        if (i >= D && j == i) v = 1.0;
+        l[i * kSmallLd + j] = v;
+    }
+    __syncthreads();
+    // Inverse of each 16x16 diagonal block: thread (b, col) solves L_bb x = e_col.
+    if (tid < NB * 16) {
+        int b = tid >> 4, col = tid & 15;
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double s = (i == col) ? 1.0 : 0.0;
+#pragma unroll
+            for (int m = 0; m < 16; ++m)
+                if (m < i) s -= l[(16 * b + i) * kSmallLd + 16 * b + m] * x[m];
+            x[i] = (i < col) ? 0.0 : s / l[(16 * b + i) * kSmallLd + 16 * b + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) linv[(b * 16 + i) * 17 + col] = x[i];
+    }
+    __syncthreads();
+    const int total = 2 * NBT * 256;
+    for (int e = tid; e < total; e += 256) {
+        int PI = e >> 8, s = (e >> 6) & 3, lane = e & 63;
+        int q = lane >> 4, rho = lane & 15;
+        bool bwd = PI >= NBT;
+        int t = bwd ? PI - NBT : PI;
+        int hi = 0;
+        while ((hi + 1) * (hi + 2) / 2 <= t) ++hi;
+        int lo = t - hi * (hi + 1) / 2;
+        // forward: j = hi (row block), i = lo.  backward: j = lo (row block), i = hi.
+        int j = bwd ? lo : hi, i = bwd ? hi : lo;
+        int row = vt_perm(j < NB - 1 || lastperm, rho);
+        int col = vt_perm(i < NB - 1 || lastperm, 4 * s + q);
+        double v;
+        if (!bwd) {
+            if (i == j) {
+                v = linv[(j * 16 + row) * 17 + col];
+            } else {
+                v = 0.0;
+                for (int m = 0; m < 16; ++m)
+                    v -= linv[(j * 16 + row) * 17 + m] * l[(16 * j + m) * kSmallLd + 16 * i + col];
+            }
+        } else {
+            if (i == j) {
+                v = linv[(j * 16 + col) * 17 + row];
+            } else {
+                v = 0.0;
+                for (int m = 0; m < 16; ++m)
+                    v -= linv[(j * 16 + m) * 17 + row] * l[(16 * i + col) * kSmallLd + 16 * j + m];
+            }
+        }
+        pack[e] = v;
+    }
+}
+
+// -------------------------------------------------------------- TRSM rows -------
+struct TrsmArgs {
+    const double* pack;
+    const double* B;
+    int64_t ldb;
+    const double* rowscale;
+    double alpha;
+    int64_t N;
+    int D;
+    double* Out;
+    int64_t ldo;
+};
+
+// Out[n,:] = alpha * s_n * (L L^T)^{-1} B[n,:].   D <= 128.
+// Each wave solves one tile of 16 right-hand sides at a time.  The right-hand sides
+// sit on the MFMA "column" (lane & 15) axis, the parameter index on the "row" axis,
+// so a solved block Y_i (an accumulator) IS the B operand of the following
+// products -- register r of the accumulator is k-step r -- and the whole forward /
+// backward substitution is a chain of v_mfma_f64_16x16x4_f64 with A operands read
+// from the LDS-resident pack.  Nothing but X (or B) is read from HBM and nothing
+// but S is written.
+//
+// The chain is a compile-time schedule of 2*NBT block products; product k+1's A
+// operands are read from LDS while product k's MFMAs run, and sched_barriers keep
+// hipcc from hoisting all ~200 ds_reads to the top (which spills hundreds of VGPRs).
+template <int NB, int KL, bool LASTPERM>
+struct TrsmSched {
+    static constexpr int NBT = NB * (NB + 1) / 2;
+    static constexpr int M = 2 * NBT;
+    static constexpr bool permuted(int b) { return b < NB - 1 || LASTPERM; }
+    static constexpr int ks(int b) { return permuted(b) ? 4 : KL; }
+    // product idx -> (backward?, row block j, source block i)
+    static constexpr bool bwd(int idx) { return idx >= NBT; }
+    static constexpr int row(int idx) {
+        if (idx < NBT) {  // forward: j = 0..NB-1, i = j..0
+            int j = 0, k = idx;
+            while (k > j) { k -= j + 1; ++j; }
+            return j;
+        }
+        int k = idx - NBT, j = NB - 1;  // backward: j = NB-1..0, i = j..NB-1
+        while (k >= NB - j) { k -= NB - j; --j; }
+        return j;
+    }
+    static constexpr int src(int idx) {
+        if (idx < NBT) {
+            int j = 0, k = idx;
+            while (k > j) { k -= j + 1; ++j; }
+            return j - k;
+        }
+        int k = idx - NBT, j = NB - 1;
+        while (k >= NB - j) { k -= NB - j; --j; }
+        return j + k;
+    }
+    static constexpr bool first(int idx) { return src(idx) == row(idx); }
+    static constexpr bool last(int idx) { return bwd(idx) ? src(idx) == NB - 1 : src(idx) == 0; }
+    // index of the pack image for this product
+    static constexpr int image(int idx) {
+        return bwd(idx) ? NBT + vt_tri(src(idx), row(idx)) : vt_tri(row(idx), src(idx));
+    }
+};
+
+template <int NB, int KL, bool LASTPERM>
+struct TrsmState {
+    f64x4 V[NB];
+    f64x4 acc;
+    double cur[4], nxt[4];
+    const double* lds;
+    int lane, q;
+    double* orow;  // output row of this lane (nullptr-safe through `store`)
+    bool store;
+    int D;
+};
+
+template <int IDX, int NB, int KL, bool LASTPERM>
+__device__ __forceinline__ void trsm_product(TrsmState<NB, KL, LASTPERM>& st) {
+    using S = TrsmSched<NB, KL, LASTPERM>;
+    if constexpr (IDX < S::M) {
+        if constexpr (IDX + 1 < S::M) {
+            constexpr int img = S::image(IDX + 1);
+#pragma unroll
+            for (int s = 0; s < S::ks(S::src(IDX + 1)); ++s) st.nxt[s] = st.lds[(img * 4 + s) * 64 + st.lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int i = S::src(IDX), j = S::row(IDX);
+        if constexpr (S::first(IDX)) st.acc = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < S::ks(i); ++s) st.acc = mfma_f64(st.cur[s], st.V[i][s], st.acc);
+        if constexpr (S::last(IDX)) {
+            st.V[j] = st.acc;
+            if constexpr (S::bwd(IDX)) {
+                if (st.store) {
+                    if constexpr (S::permuted(j)) {
+                        *(f64x2u*)(st.orow + 16 * j + 4 * st.q) = (f64x2u){st.acc[0], st.acc[1]};
+                        *(f64x2u*)(st.orow + 16 * j + 4 * st.q + 2) = (f64x2u){st.acc[2], st.acc[3]};
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < KL; ++s) {
+                            int col = 16 * j + 4 * s + st.q;
+                            if (col < st.D) st.orow[col] = st.acc[s];
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) st.cur[s] = st.nxt[s];
+        trsm_product<IDX + 1, NB, KL, LASTPERM>(st);
+    }
+}
+
+template <int NB, int KL, bool LASTPERM, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
+    using S = TrsmSched<NB, KL, LASTPERM>;
+    constexpr int NBT = S::NBT;
+    __shared__ double lds[2 * NBT * 256];
+    {
+        const f64x2u* src = (const f64x2u*)a.pack;
+        f64x2u* dst = (f64x2u*)lds;
+        for (int i = threadIdx.x; i < NBT * 256; i += WAVES * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int64_t W = (int64_t)gridDim.x * WAVES;
+    const int64_t gw = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t ngroups = (a.N + 15) / 16;
+
+    TrsmState<NB, KL, LASTPERM> st;
+    st.lds = lds;
+    st.lane = lane;
+    st.q = q;
+    st.D = a.D;
+
+    f64x4 Gn[NB];  // next tile's right-hand side (prefetch)
+    double coefn;
+
+    // Unconditional loads with clamped indices (no branch per load): rows past N
+    // re-read row N-1 and are zeroed through coef = 0.
+    auto load_group = [&](int64_t grp) {
+        int64_t row = grp * 16 + n;
+        bool rowok = row < a.N;
+        int64_t rowc = rowok ? row : a.N - 1;
+        const double* br = a.B + rowc * a.ldb;
+        double sc = a.rowscale ? a.rowscale[rowc] : 1.0;
+        coefn = rowok ? a.alpha * sc : 0.0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            f64x4 v = {0.0, 0.0, 0.0, 0.0};
+            if constexpr (S::permuted(NB - 1)) {
+                f64x2u lo = *(const f64x2u*)(br + 16 * b + 4 * q);
+                f64x2u hi = *(const f64x2u*)(br + 16 * b + 4 * q + 2);
+                v = (f64x4){lo[0], lo[1], hi[0], hi[1]};
+            } else {
+                if (b < NB - 1) {
+                    f64x2u lo = *(const f64x2u*)(br + 16 * b + 4 * q);
+                    f64x2u hi = *(const f64x2u*)(br + 16 * b + 4 * q + 2);
+                    v = (f64x4){lo[0], lo[1], hi[0], hi[1]};
+                } else {
+#pragma unroll
+                    for (int s = 0; s < KL; ++s) {
+                        int col = 16 * b + 4 * s + q;
+                        double x = br[min(col, a.D - 1)];
+                        v[s] = col < a.D ? x : 0.0;
+                    }
+                }
+            }
+            Gn[b] = v;
+        }
+    };
+
+    int64_t grp = gw;
+    if (grp < ngroups) load_group(grp);
+    for (; grp < ngroups; grp += W) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) st.V[b] = Gn[b] * coefn;
+        int64_t row = grp * 16 + n;
+        st.store = row < a.N;
+        st.orow = a.Out + (st.store ? row : 0) * a.ldo;
+        load_group(grp + W < ngroups ? grp + W : grp);
+        {
+            constexpr int img = S::image(0);
+#pragma unroll
+            for (int s = 0; s < S::ks(S::src(0)); ++s) st.cur[s] = lds[(img * 4 + s) * 64 + lane];
+        }
+        trsm_product<0, NB, KL, LASTPERM>(st);
+    }
+}
+
+int g_cu = 0;
+int num_cu() {
+    if (g_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        g_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return g_cu;
+}
+
+// Two waves per SIMD, one 16-row tile each: everything a wave keeps outside the
+// accumulator must fit the 256 architectural VGPRs, and the partner wave's MFMA
+// chain fills this wave's load / dependency stalls.
+constexpr int kTrsmWaves = 8;
+
+template <int NB, int KL, bool LASTPERM>
+void launch_trsm(const TrsmArgs& a, hipStream_t st) {
+    int64_t ngroups = (a.N + 15) / 16;
+    int64_t g = (ngroups + kTrsmWaves - 1) / kTrsmWaves;
+    if (g > num_cu()) g = num_cu();
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL((k_trsm_rows_small<NB, KL, LASTPERM, kTrsmWaves>), dim3((int)g),
+                       dim3(kTrsmWaves * 64), 0, st, a);
+}
+
+template <int NB>
+int dispatch_trsm_kl(const TrsmArgs& a, hipStream_t st) {
+    int rem = a.D - 16 * (NB - 1);  // 1..16 columns in the last block
+    if (rem == 16) {
+        launch_trsm<NB, 4, true>(a, st);
+        return VT_OK;
+    }
+    switch ((rem + 3) / 4) {
+        case 1: launch_trsm<NB, 1, false>(a, st); break;
+        case 2: launch_trsm<NB, 2, false>(a, st); break;
+        case 3: launch_trsm<NB, 3, false>(a, st); break;
+        default: launch_trsm<NB, 4, false>(a, st); break;
+    }
+    return VT_OK;
+}
+
+}  // namespace
+
+extern "C" size_t vt_potrf_workspace_bytes(int D) {
+    (void)D;
+    return 0;
+}
+
+extern "C" int vt_potrf(double* A, int lda, int D, int* info, void* ws, size_t ws_bytes, void* stream) {
+    (void)ws;
+    (void)ws_bytes;
+    if (!A || !info || D < 1 || lda < D) return VT_ERR_BAD_ARG;
+    if (D > VT_SMALL_D_MAX) return VT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_potrf_small, dim3(1), dim3(512), 0, (hipStream_t)stream, A, lda, D, info);
+    return vt_launch_status();
+}
+
+extern "C" int vt_potrs(const double* L, int ldl, int D, double* B, int64_t ldb_row, int64_t ldb_col,
+                        int64_t nrhs, void* stream) {
+    if (!L || !B || D < 1 || ldl < D || nrhs < 0) return VT_ERR_BAD_ARG;
+    if (nrhs == 0) return VT_OK;
+    size_t shmem = (size_t)D * sizeof(double);
+    if (shmem > 160 * 1024) return VT_ERR_UNSUPPORTED;
+    if (shmem > 64 * 1024)
+        VT_CHECK_HIP(hipFuncSetAttribute((const void*)k_potrs_generic, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)shmem));
+    int64_t grid = nrhs < 4096 ? nrhs : 4096;
+    hipLaunchKernelGGL(k_potrs_generic, dim3((int)grid), dim3(64), shmem, (hipStream_t)stream, L, ldl, D, B,
+                       ldb_row, ldb_col, nrhs);
+    return vt_launch_status();
+}
+
+extern "C" size_t vt_trsm_pack_bytes(int D) {
+    if (D < 1 || D > VT_SMALL_D_MAX) return 0;
+    int NB = (D + 15) / 16;
+    return (size_t)2 * (NB * (NB + 1) / 2) * 256 * sizeof(double);
+}
+
+extern "C" int vt_trsm_pack(const double* L, int ldl, int D, void* pack, void* stream) {
+    if (!L || !pack || D < 1 || ldl < D) return VT_ERR_BAD_ARG;
+    if (D > VT_SMALL_D_MAX) return VT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_trsm_pack, dim3(1), dim3(256), 0, (hipStream_t)stream, L, ldl, D, (double*)pack);
+    return vt_launch_status();
+}
+
+extern "C" int vt_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale,
+                            double alpha, int64_t N, double* Out, int64_t ldo, void* stream) {
+    if (!pack || !B || !Out || D < 1 || ldb < D || ldo < D || N < 0) return VT_ERR_BAD_ARG;
+    if (D > VT_SMALL_D_MAX) return VT_ERR_UNSUPPORTED;
+    if (N == 0) return VT_OK;
+    TrsmArgs a{(const double*)pack, B, ldb, rowscale, alpha, N, D, Out, ldo};
+    hipStream_t st = (hipStream_t)stream;
+    switch ((D + 15) / 16) {
+        case 1: dispatch_trsm_kl<1>(a, st); break;
+        case 2: dispatch_trsm_kl<2>(a, st); break;
+        case 3: dispatch_trsm_kl<3>(a, st); break;
+        case 4: dispatch_trsm_kl<4>(a, st); break;
+        case 5: dispatch_trsm_kl<5>(a, st); break;
+        case 6: dispatch_trsm_kl<6>(a, st); break;
+        case 7: dispatch_trsm_kl<7>(a, st); break;
+        case 8: dispatch_trsm_kl<8>(a, st); break;
+        default: return VT_ERR_UNSUPPORTED;
+    }
+    return vt_launch_status();
+}

@@ -1,0 +1,84 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vittles_hip.h"
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+// 16-byte vector of two doubles that is only guaranteed 8-byte aligned (rows of X
+// are 8-byte aligned for odd D); gfx950 global loads/stores need dword alignment.
+typedef double f64x2u __attribute__((ext_vector_type(2), aligned(8)));
+
+#define VT_WAVE 64
+
+#define VT_CHECK_HIP(expr)                         \
+    do {                                           \
+        hipError_t _e = (expr);                    \
+        if (_e != hipSuccess) return VT_ERR_HIP;   \
+    } while (0)
+
+static inline int vt_launch_status() {
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) * B(4x16), one f64 of A and B per lane.
+//   A operand: lane l holds A[i = l & 15][k = l >> 4]
+//   B operand: lane l holds B[k = l >> 4][j = l & 15]
+//   C/D      : lane l, register r holds D[i = (l >> 4) + 4 r][j = l & 15]
+// (f64 does NOT use the f32/bf16 C/D map; cdna_hip_programming.md section 3.)
+__device__ __forceinline__ f64x4 mfma_f64(double a, double b, f64x4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int vt_nblocks(int D) { return (D + 15) >> 4; }
+
+// Per-row link derivatives: l1 = ell'(z), l2 = ell''(z).
+__device__ __forceinline__ void vt_link(int family, double z, double y, double& l1, double& l2) {
+    if (family == VT_FAMILY_LOGISTIC) {
+        // p = sigmoid(z), evaluated on the stable side
+        double e = exp(-fabs(z));
+        double inv = 1.0 / (1.0 + e);
+        double p = z >= 0.0 ? inv : e * inv;
+        l1 = p - y;
+        l2 = e * inv * inv;  // p (1 - p) without cancellation
+    } else if (family == VT_FAMILY_POISSON) {
+        double e = exp(z);
+        l1 = e - y;
+        l2 = e;
+    } else {
+        l1 = z - y;
+        l2 = 1.0;
+    }
+}
+
+// Per-row loss value ell(z, y).
+__device__ __forceinline__ double vt_loss(int family, double z, double y) {
+    if (family == VT_FAMILY_LOGISTIC) {
+        return fmax(z, 0.0) + log1p(exp(-fabs(z))) - y * z;
+    } else if (family == VT_FAMILY_POISSON) {
+        return exp(z) - y * z;
+    } else {
+        double t = z - y;
+        return 0.5 * t * t;
+    }
+}
+
+// Sum over the 16 lanes that share (lane >> 4); every lane gets the total.
+__device__ __forceinline__ double vt_sum16(double v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// Sum over all 64 lanes; every lane gets the total.
+__device__ __forceinline__ double vt_sum64(double v) {
+    v = vt_sum16(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// Index of the (a, b) block, a >= b, in packed lower-triangular block order.
+__host__ __device__ __forceinline__ constexpr int vt_tri(int a, int b) { return a * (a + 1) / 2 + b; }

@@ -1,0 +1,22 @@
+// Library-level entry points: version, error strings, device probe.
+#include "vt_common.h"
+
+extern "C" int vt_version(void) { return 100; }
+
+extern "C" const char* vt_error_string(int code) {
+    switch (code) {
+        case VT_OK: return "ok";
+        case VT_ERR_BAD_ARG: return "bad argument (null pointer, negative size or leading dimension too small)";
+        case VT_ERR_UNSUPPORTED: return "shape not supported by the HIP kernels";
+        case VT_ERR_WORKSPACE: return "workspace missing or too small (see *_workspace_bytes)";
+        case VT_ERR_HIP: return "a HIP runtime call or kernel launch failed";
+        case VT_ERR_NO_DEVICE: return "no HIP device";
+        default: return code > 0 ? "LAPACK-style info > 0" : "unknown error";
+    }
+}
+
+extern "C" int vt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return VT_ERR_NO_DEVICE;
+    return n;
+}

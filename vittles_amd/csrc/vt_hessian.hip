@@ -1,0 +1,285 @@
+// K0 + K1 + K3 fused for the weighted-GLM objective: ONE pass over X produces
+//   H = X^T diag(d) X (+ prior),  g = X^T (w r) (+ prior theta),  r, d per row.
+// Replaces autograd.hessian / autograd.grad of the reference
+// (vittles/sensitivity_lib.py:354, 381-383) -- see include/vittles_hip.h.
+//
+// Small-D kernel (D <= 128, NB = ceil(D/16) <= 8 column blocks)
+// -----------------------------------------------------------------
+// A weighted SYRK whose K dimension is N: every wave owns the WHOLE lower block
+// triangle of H in registers (NB(NB+1)/2 accumulators of v_mfma_f64_16x16x4_f64)
+// and streams rows of X straight from HBM into the MFMA operand layout:
+//   k-step = 4 consecutive rows; lane l = (q = l>>4, c = l&15) loads X[row q][16a + c]
+//   for every column block a -- 16 lanes read 128 contiguous bytes of one row.
+//   The same register is the A operand (x) and, scaled by d_n, the B operand.
+// No LDS staging is needed and X is read exactly once.  The row dot x_n.theta
+// (link), the gradient accumulation and the per-row factors ride along in VALU
+// slots beside the MFMAs.  Partials are reduced deterministically (no fp64
+// atomics): 4 waves -> 1 through LDS, then a fixed-order tree over workgroups.
+#include "vt_common.h"
+
+namespace {
+
+struct HessArgs {
+    int family;
+    const double* X;
+    int64_t ldx;
+    const double* theta;
+    const double* y;
+    const double* w;
+    const double* offset;
+    double scale;
+    int64_t N;
+    int D;
+    double* r_out;
+    double* d_out;
+    double* part;       // [gridDim.x][L] partial slabs, L = NBT*256 + NB*16
+    double* wave_part;  // [gridDim.x][4][NBT*256] per-wave slabs
+};
+
+// Loads are UNCONDITIONAL with clamped row / column indices (a per-element
+// "load or zero" select makes hipcc branch around every load and drain vmcnt):
+// out-of-range rows re-read row N-1 and are neutralised by d_n = 0, out-of-range
+// columns re-read column D-1 and land in padded rows/columns that are never stored.
+template <int NB>
+__device__ __forceinline__ void load_step(const HessArgs& a, int64_t step, int q, int c, double (&x)[NB]) {
+    int64_t n = step * 4 + q;
+    n = n < a.N ? n : a.N - 1;
+    const double* xr = a.X + n * a.ldx;
+    const int clast = min(16 * (NB - 1) + c, a.D - 1);
+#pragma unroll
+    for (int b = 0; b < NB - 1; ++b) x[b] = xr[16 * b + c];
+    x[NB - 1] = xr[clast];
+}
+
+template <int NB, int FAM, bool HAS_OFF>
+__global__ __launch_bounds__(256) void k_glm_hess_small(HessArgs a) {
+    constexpr int NBT = NB * (NB + 1) / 2;
+    constexpr int L = NBT * 256 + NB * 16;
+    __shared__ double gl[4 * NB * 16];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    const int64_t nsteps = (a.N + 3) >> 2;
+    const int64_t W = (int64_t)gridDim.x * 4;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+
+    double th[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) th[b] = (16 * b + c < a.D) ? a.theta[16 * b + c] : 0.0;
+
+    f64x4 acc[NBT];
+#pragma unroll
+    for (int i = 0; i < NBT; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    double gacc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) gacc[b] = 0.0;
+
+    auto compute = [&](int64_t step, const double (&x)[NB]) {
+        int64_t n = step * 4 + q;
+        bool rowok = (step < nsteps) && (n < a.N);
+        double p = 0.0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) p = fma(x[b], th[b], p);
+        double z = vt_sum16(p);
+        int64_t nc = n < a.N ? n : a.N - 1;
+        double yv = a.y[nc], wv = a.w[nc];
+        if (HAS_OFF) z += a.offset[nc];
+        double l1, l2;
+        vt_link(FAM, z, yv, l1, l2);
+        double rr = a.scale * l1;
+        double dw = rowok ? a.scale * wv * l2 : 0.0;
+        double gwt = rowok ? wv * rr : 0.0;
+        if (rowok && c == 0) {
+            if (a.r_out) a.r_out[n] = rr;
+            if (a.d_out) a.d_out[n] = dw;
+        }
+        double bb[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            gacc[b] = fma(gwt, x[b], gacc[b]);
+            bb[b] = dw * x[b];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) acc[vt_tri(i, j)] = mfma_f64(x[i], bb[j], acc[vt_tri(i, j)]);
+    };
+
+    // 3-deep register prefetch ring over this wave's interleaved k-steps.
+    double x0[NB], x1[NB], x2[NB];
+    int64_t s = gw;
+    load_step<NB>(a, s, q, c, x0);
+    load_step<NB>(a, s + W, q, c, x1);
+    load_step<NB>(a, s + 2 * W, q, c, x2);
+    for (; s < nsteps; s += 3 * W) {
+        compute(s, x0);
+        load_step<NB>(a, s + 3 * W, q, c, x0);
+        compute(s + W, x1);
+        load_step<NB>(a, s + 4 * W, q, c, x1);
+        compute(s + 2 * W, x2);
+        load_step<NB>(a, s + 5 * W, q, c, x2);
+    }
+
+    // ---- gradient: sum the 4 row groups of the wave, then the 4 waves ----------
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        double v = gacc[b];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (q == 0) gl[wave * (NB * 16) + 16 * b + c] = v;
+    }
+
+    // ---- H accumulators: 4 waves -> 1 -------------------------------------------
+    // The accumulators leave the AGPR file only through GLOBAL stores: a ds_write
+    // (or any VALU op) on them makes hipcc keep all of them in VGPRs for the whole
+    // kernel and spill everything else.  Each wave parks its slab in the workspace
+    // (L2-resident), the workgroup then folds its 4 slabs into one.
+    double* wslab = a.wave_part + (int64_t)blockIdx.x * 4 * (NBT * 256);
+    {
+        double* mine = wslab + wave * (NBT * 256);
+#pragma unroll
+        for (int i = 0; i < NBT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(i * 4 + r) * 64 + lane] = acc[i][r];
+    }
+    __syncthreads();
+    double* out = a.part + (int64_t)blockIdx.x * L;
+    for (int e = threadIdx.x; e < NBT * 256; e += 256)
+        out[e] = (wslab[e] + wslab[NBT * 256 + e]) + (wslab[2 * NBT * 256 + e] + wslab[3 * NBT * 256 + e]);
+    for (int t = threadIdx.x; t < NB * 16; t += 256)
+        out[NBT * 256 + t] = (gl[t] + gl[NB * 16 + t]) + (gl[2 * NB * 16 + t] + gl[3 * NB * 16 + t]);
+}
+
+// Sum `per` consecutive partial slabs into one: out[p][e] = sum_{k<per} in[p*per + k][e].
+__global__ void k_reduce_slabs(const double* in, double* out, int L, int P_in, int per) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    int p = blockIdx.y;
+    if (e >= L) return;
+    double s = 0.0;
+    int k0 = p * per, k1 = min(P_in, k0 + per);
+    for (int k = k0; k < k1; ++k) s += in[(int64_t)k * L + e];
+    out[(int64_t)p * L + e] = s;
+}
+
+// Final: sum the remaining slabs, undo the accumulator layout, mirror the
+// triangle, add the prior.  One thread per accumulator element / gradient entry.
+__global__ void k_hess_finalize(const double* in, int L, int P, int NB, int D,
+                                const double* prior, const double* theta,
+                                double* H, int ldh, double* g) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= L) return;
+    double s = 0.0;
+    for (int k = 0; k < P; ++k) s += in[(int64_t)k * L + e];
+    int NBT = NB * (NB + 1) / 2;
+    if (e < NBT * 256) {
+        int blk = e >> 8, r = (e >> 6) & 3, lane = e & 63;
+        int ba = 0;
+        while ((ba + 1) * (ba + 2) / 2 <= blk) ++ba;
+        int bb = blk - ba * (ba + 1) / 2;
+        int i = 16 * ba + (lane >> 4) + 4 * r;
+        int j = 16 * bb + (lane & 15);
+        if (i < D && j < D) {
+            if (i == j && prior) s += prior[i];
+            if (ba != bb || i >= j) {
+                H[(int64_t)i * ldh + j] = s;
+                H[(int64_t)j * ldh + i] = s;
+            }
+        }
+    } else if (g) {
+        int t = e - NBT * 256;
+        if (t < D) g[t] = s + (prior ? prior[t] * theta[t] : 0.0);
+    }
+}
+
+int g_num_cu = 0;
+int num_cu() {
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return g_num_cu;
+}
+
+constexpr int kStage2 = 16;
+
+inline int slab_len(int NB) { return NB * (NB + 1) / 2 * 256 + NB * 16; }
+
+inline int hess_grid(int64_t N) {
+    int64_t nsteps = (N + 3) / 4;
+    int64_t g = (nsteps + 15) / 16;  // >= 4 k-steps per wave before adding workgroups
+    int cu = num_cu();
+    if (g > cu) g = cu;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <int NB, int FAM>
+void launch_hess_small2(const HessArgs& a, int grid, hipStream_t st) {
+    if (a.offset)
+        hipLaunchKernelGGL((k_glm_hess_small<NB, FAM, true>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_glm_hess_small<NB, FAM, false>), dim3(grid), dim3(256), 0, st, a);
+}
+
+template <int NB>
+void launch_hess_small(const HessArgs& a, int grid, hipStream_t st) {
+    switch (a.family) {
+        case VT_FAMILY_LOGISTIC: launch_hess_small2<NB, VT_FAMILY_LOGISTIC>(a, grid, st); break;
+        case VT_FAMILY_POISSON: launch_hess_small2<NB, VT_FAMILY_POISSON>(a, grid, st); break;
+        default: launch_hess_small2<NB, VT_FAMILY_GAUSSIAN>(a, grid, st); break;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t vt_glm_hessian_workspace_bytes(int64_t N, int D) {
+    if (D < 1 || D > VT_SMALL_D_MAX) return 0;
+    int NB = (D + 15) / 16;
+    return ((size_t)(num_cu() + kStage2) * slab_len(NB) + (size_t)num_cu() * 4 * (NB * (NB + 1) / 2) * 256) *
+           sizeof(double);
+}
+
+extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const double* theta,
+                              const double* y, const double* w, const double* offset, double scale,
+                              const double* prior, int64_t N, int D, double* H, int ldh, double* g,
+                              double* r, double* d, void* ws, size_t ws_bytes, void* stream) {
+    if (!X || !theta || !y || !w || !H || N < 0 || D < 1 || ldx < D || ldh < D) return VT_ERR_BAD_ARG;
+    if (family < 0 || family > 2) return VT_ERR_BAD_ARG;
+    if (D > VT_SMALL_D_MAX) return VT_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < vt_glm_hessian_workspace_bytes(N, D)) return VT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int NB = (D + 15) / 16;
+    const int L = slab_len(NB);
+    const int grid = hess_grid(N);
+    double* part = (double*)ws;
+    double* part2 = part + (size_t)num_cu() * L;
+    double* wave_part = part2 + (size_t)kStage2 * L;
+
+    HessArgs a{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, wave_part};
+    switch (NB) {
+        case 1: launch_hess_small<1>(a, grid, st); break;
+        case 2: launch_hess_small<2>(a, grid, st); break;
+        case 3: launch_hess_small<3>(a, grid, st); break;
+        case 4: launch_hess_small<4>(a, grid, st); break;
+        case 5: launch_hess_small<5>(a, grid, st); break;
+        case 6: launch_hess_small<6>(a, grid, st); break;
+        case 7: launch_hess_small<7>(a, grid, st); break;
+        case 8: launch_hess_small<8>(a, grid, st); break;
+        default: return VT_ERR_UNSUPPORTED;
+    }
+    const double* fin = part;
+    int P = grid;
+    if (P > kStage2) {
+        int per = (P + kStage2 - 1) / kStage2;
+        int P2 = (P + per - 1) / per;
+        hipLaunchKernelGGL(k_reduce_slabs, dim3((L + 255) / 256, P2), dim3(256), 0, st, part, part2, L, P, per);
+        fin = part2;
+        P = P2;
+    }
+    hipLaunchKernelGGL(k_hess_finalize, dim3((L + 255) / 256), dim3(256), 0, st, fin, L, P, NB, D, prior, theta,
+                       H, ldh, g);
+    return vt_launch_status();
+}

@@ -1,0 +1,378 @@
+// Row-streaming kernels (HBM-bound): K0 link, K3 gradient, K6 fused HVP, K9 predict,
+// objective value.  All share one shape:
+//     for every row n:  dot_n = x_n . v     (optional)
+//                       t_n   = op(dot_n, per-row scalars)      -> per-row outputs
+//                       out  += t_n * x_n   (optional, D-vector)
+//                       val  += s_n         (optional, scalar)
+// with X read exactly ONCE: a TEAM of threads holds the whole row in registers
+// between the dot and the rank-1 accumulation (16-byte coalesced loads, one row =
+// TEAM * CPT * 16 bytes), the D-vector accumulator lives in registers for the whole
+// kernel, and partial results are combined by a fixed-order two-stage reduction
+// (no fp64 atomics -> bitwise reproducible).
+//
+// Replaces, for registered GLM objectives:
+//   autograd.grad(objective)(theta, w)                 vittles/sensitivity_lib.py:354,203-209
+//   the user's `mat_times_vec` HVP handed to get_cg_solver  vittles/solver_lib.py:70-98
+//   `self._sens_mat @ (new_hyper - hyper0)`            vittles/sensitivity_lib.py:245-247
+#include "vt_common.h"
+
+namespace {
+
+enum RowOp { OP_LINK = 0, OP_GRAD = 1, OP_HVP = 2, OP_GEMVT = 3, OP_VALUE = 4, OP_GEMV = 5 };
+
+struct RowArgs {
+    const double* X;
+    int64_t ldx;
+    int64_t N;
+    int D;
+    const double* v;       // D-vector for the dot (theta / CG direction); may be NULL
+    const double* y;       // per-row inputs (meaning depends on op)
+    const double* w;
+    const double* offset;
+    const double* dvec;    // HVP: precomputed d_n;  GEMVT: the N-vector
+    double scale;
+    int family;
+    double* z_out;         // per-row outputs
+    double* r_out;
+    double* d_out;
+    double* part;          // [gridDim.x][D (+1)] partial column sums (+ value)
+};
+
+template <int OP>
+struct OpTraits {
+    static constexpr bool kDot = OP != OP_GEMVT;
+    static constexpr bool kCols = OP == OP_GRAD || OP == OP_HVP || OP == OP_GEMVT;
+    static constexpr bool kVal = OP == OP_VALUE;
+};
+
+// Per-row scalar stage.  Returns the coefficient of x_n in the column accumulation.
+template <int OP>
+__device__ __forceinline__ double row_op(const RowArgs& a, int64_t n, double dot, bool lead, double& val) {
+    if constexpr (OP == OP_GEMVT) {
+        return a.dvec[n];
+    } else if constexpr (OP == OP_GEMV) {
+        if (lead) a.z_out[n] = dot;
+        return 0.0;
+    } else if constexpr (OP == OP_HVP) {
+        return a.dvec[n] * dot;
+    } else {
+        double z = dot + (a.offset ? a.offset[n] : 0.0);
+        double yv = a.y[n], wv = a.w[n];
+        if constexpr (OP == OP_VALUE) {
+            if (lead) val += wv * vt_loss(a.family, z, yv);
+            return 0.0;
+        } else {
+            double l1, l2;
+            vt_link(a.family, z, yv, l1, l2);
+            double rr = a.scale * l1;
+            if (lead) {
+                if (a.z_out) a.z_out[n] = z;
+                if (a.r_out) a.r_out[n] = rr;
+                if (a.d_out) a.d_out[n] = a.scale * wv * l2;
+            }
+            return wv * rr;
+        }
+    }
+}
+
+// TEAM threads per row, each owning CPT chunks of VEC doubles: column of element e of
+// chunk k = VEC * (tt + TEAM * k) + e.   WG = max(TEAM, 256) threads.
+template <int OP, int TEAM, int CPT, int VEC>
+__global__ __launch_bounds__((TEAM > 256 ? TEAM : 256)) void k_rows(RowArgs a) {
+    constexpr int WG = TEAM > 256 ? TEAM : 256;
+    constexpr int TEAMS = WG / TEAM;
+    constexpr int NE = CPT * VEC;
+    using T = OpTraits<OP>;
+    __shared__ double red[WG / 64 + 1];
+    extern __shared__ double dyn[];  // cross-team column reduction (TEAMS > 1)
+
+    const int tid = threadIdx.x;
+    const int tt = tid % TEAM;
+    const int team = tid / TEAM;
+    const int lane = tid & 63;
+    const int64_t total_teams = (int64_t)gridDim.x * TEAMS;
+    const int64_t gteam = (int64_t)blockIdx.x * TEAMS + team;
+
+    // column offsets (clamped so that every load is in-bounds) and the dot vector
+    int coff[CPT];
+    double vv[NE];
+    double acc[NE];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        int c0 = VEC * (tt + TEAM * k);
+        coff[k] = min(c0, a.D - VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            vv[k * VEC + e] = (T::kDot && c0 + e < a.D) ? a.v[c0 + e] : 0.0;
+            acc[k * VEC + e] = 0.0;
+        }
+    }
+    double val = 0.0;
+
+    const int64_t iters = (a.N + total_teams - 1) / total_teams;
+    for (int64_t it = 0; it < iters; ++it) {
+        int64_t n = gteam + it * total_teams;
+        bool valid = n < a.N;
+        int64_t nc = valid ? n : a.N - 1;
+        const double* xr = a.X + nc * a.ldx;
+        double x[NE];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            if constexpr (VEC == 2) {
+                f64x2u t = *(const f64x2u*)(xr + coff[k]);
+                x[2 * k] = t[0];
+                x[2 * k + 1] = t[1];
+            } else {
+                x[k] = xr[coff[k]];
+            }
+        }
+        double dot = 0.0;
+        if constexpr (T::kDot) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) dot = fma(x[i], vv[i], dot);
+            if constexpr (TEAM == 16) {
+                dot = vt_sum16(dot);
+            } else {
+                dot = vt_sum64(dot);
+                if constexpr (TEAM > 64) {
+                    __syncthreads();
+                    if (lane == 0) red[tid >> 6] = dot;
+                    __syncthreads();
+                    dot = 0.0;
+#pragma unroll
+                    for (int i = 0; i < TEAM / 64; ++i) dot += red[i];
+                }
+            }
+        }
+        double dummy = 0.0;
+        double t = row_op<OP>(a, nc, dot, valid && tt == 0, valid ? val : dummy);
+        if (!valid) t = 0.0;
+        if constexpr (T::kCols) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) acc[i] = fma(t, x[i], acc[i]);
+        }
+    }
+
+    // ---- combine within the workgroup, write the partial ------------------------
+    const int PL = a.D + 1;
+    double* out = a.part + (int64_t)blockIdx.x * PL;
+    if constexpr (T::kCols) {
+        if constexpr (TEAMS > 1) {
+            const int DP = TEAM * CPT * VEC;  // padded row length covered by a team
+#pragma unroll
+            for (int k = 0; k < CPT; ++k)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) dyn[team * DP + VEC * (tt + TEAM * k) + e] = acc[k * VEC + e];
+            __syncthreads();
+            for (int c = tid; c < a.D; c += WG) {
+                double s = 0.0;
+                for (int g = 0; g < TEAMS; ++g) s += dyn[g * DP + c];
+                out[c] = s;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    int c = VEC * (tt + TEAM * k) + e;
+                    if (c < a.D) out[c] = acc[k * VEC + e];
+                }
+        }
+    }
+    if constexpr (T::kVal) {
+        // only team leaders accumulated `val`
+        double s = vt_sum64(val);
+        __syncthreads();
+        if (lane == 0) red[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int i = 0; i < WG / 64; ++i) tot += red[i];
+            out[a.D] = tot;
+        }
+    }
+}
+
+// out[c] = alpha * sum_p part[p][c] + beta[c] * bvec[c]   (c < L);  fixed order.
+__global__ void k_rows_finalize(const double* part, int PL, int P, int L, int off, double alpha,
+                                const double* beta, const double* bvec, double beta_scalar, double* out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= L) return;
+    double s = 0.0;
+    for (int p = 0; p < P; ++p) s += part[(int64_t)p * PL + off + c];
+    s *= alpha;
+    if (bvec) s += (beta ? beta[c] : beta_scalar) * bvec[c];
+    out[c] = s;
+}
+
+int g_cu = 0;
+int num_cu() {
+    if (g_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        g_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return g_cu;
+}
+
+struct RowCfg {
+    int team, cpt, vec, wg, teams;
+};
+
+// Pick the smallest team that covers D with the compiled chunk counts.
+bool pick_cfg(int D, bool vec2, RowCfg& c) {
+    const int vec = vec2 ? 2 : 1;
+    struct Opt { int team, cpt; };
+    static const Opt opts[] = {{16, 1}, {16, 2}, {16, 4}, {64, 2}, {64, 4}, {64, 8},
+                               {256, 4}, {256, 8}, {1024, 5}, {1024, 10}, {1024, 20}};
+    for (const Opt& o : opts) {
+        if ((int64_t)o.team * o.cpt * vec >= D && !(vec2 && o.cpt > 10)) {
+            c.team = o.team;
+            c.cpt = o.cpt;
+            c.vec = vec;
+            c.wg = o.team > 256 ? o.team : 256;
+            c.teams = c.wg / o.team;
+            return true;
+        }
+    }
+    return false;
+}
+
+int max_grid() { return num_cu() * 4; }
+
+template <int OP, int TEAM, int CPT, int VEC>
+void launch_one(const RowArgs& a, int grid, hipStream_t st) {
+    constexpr int WG = TEAM > 256 ? TEAM : 256;
+    constexpr int TEAMS = WG / TEAM;
+    size_t shmem = TEAMS > 1 ? (size_t)TEAMS * TEAM * CPT * VEC * sizeof(double) : 0;
+    hipLaunchKernelGGL((k_rows<OP, TEAM, CPT, VEC>), dim3(grid), dim3(WG), shmem, st, a);
+}
+
+template <int OP, int VEC>
+int launch_cfg(const RowArgs& a, const RowCfg& c, int grid, hipStream_t st) {
+#define VT_CASE(TEAM, CPT)                                   \
+    if (c.team == TEAM && c.cpt == CPT) {                    \
+        launch_one<OP, TEAM, CPT, VEC>(a, grid, st);         \
+        return VT_OK;                                        \
+    }
+    VT_CASE(16, 1) VT_CASE(16, 2) VT_CASE(16, 4) VT_CASE(64, 2) VT_CASE(64, 4) VT_CASE(64, 8)
+    VT_CASE(256, 4) VT_CASE(256, 8) VT_CASE(1024, 5) VT_CASE(1024, 10)
+    if constexpr (VEC == 1) { VT_CASE(1024, 20) }
+#undef VT_CASE
+    return VT_ERR_UNSUPPORTED;
+}
+
+// Run one row op.  Returns the number of partial slabs written (>0) or an error (<0).
+template <int OP>
+int run_rows(RowArgs a, hipStream_t st) {
+    bool vec2 = (a.D % 2 == 0) && (a.ldx % 2 == 0) && (((uintptr_t)a.X) % 16 == 0);
+    RowCfg c;
+    if (!pick_cfg(a.D, vec2, c)) return VT_ERR_UNSUPPORTED;
+    int64_t want = (a.N + c.teams - 1) / c.teams;
+    // 1024-thread workgroups: one per CU; 256-thread: up to 4 per CU.
+    int cap = c.wg == 1024 ? num_cu() : max_grid();
+    int grid = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
+    int rc = vec2 ? launch_cfg<OP, 2>(a, c, grid, st) : launch_cfg<OP, 1>(a, c, grid, st);
+    if (rc != VT_OK) return rc;
+    if (hipGetLastError() != hipSuccess) return VT_ERR_HIP;
+    return grid;
+}
+
+int finalize(const double* part, int D, int P, int L, int off, double alpha, const double* beta,
+             const double* bvec, double beta_scalar, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_rows_finalize, dim3((L + 255) / 256), dim3(256), 0, st, part, D + 1, P, L, off, alpha,
+                       beta, bvec, beta_scalar, out);
+    return vt_launch_status();
+}
+
+}  // namespace
+
+extern "C" size_t vt_rows_workspace_bytes(int D) {
+    return (size_t)max_grid() * (D + 1) * sizeof(double);
+}
+
+#define VT_ROWS_PROLOGUE                                                                  \
+    if (!X || N < 0 || D < 1 || ldx < D) return VT_ERR_BAD_ARG;                           \
+    if (!ws || ws_bytes < vt_rows_workspace_bytes(D)) return VT_ERR_WORKSPACE;            \
+    hipStream_t st = (hipStream_t)stream;
+
+extern "C" int vt_glm_link(int family, const double* X, int64_t ldx, const double* theta, const double* y,
+                           const double* w, const double* offset, double scale, int64_t N, int D,
+                           double* z_out, double* r_out, double* d_out, void* ws, size_t ws_bytes,
+                           void* stream) {
+    VT_ROWS_PROLOGUE
+    if (!theta || !y || !w) return VT_ERR_BAD_ARG;
+    if (N == 0) return VT_OK;
+    RowArgs a{X, ldx, N, D, theta, y, w, offset, nullptr, scale, family, z_out, r_out, d_out, (double*)ws};
+    int P = run_rows<OP_LINK>(a, st);
+    return P < 0 ? P : VT_OK;
+}
+
+extern "C" int vt_glm_grad(int family, const double* X, int64_t ldx, const double* theta, const double* y,
+                           const double* w, const double* offset, double scale, const double* prior,
+                           int64_t N, int D, double* g_out, double* r_out, double* d_out, void* ws,
+                           size_t ws_bytes, void* stream) {
+    VT_ROWS_PROLOGUE
+    if (!theta || !y || !w || !g_out) return VT_ERR_BAD_ARG;
+    int P = 0;
+    if (N > 0) {
+        RowArgs a{X, ldx, N, D, theta, y, w, offset, nullptr, scale, family, nullptr, r_out, d_out, (double*)ws};
+        P = run_rows<OP_GRAD>(a, st);
+        if (P < 0) return P;
+    }
+    return finalize((const double*)ws, D, P, D, 0, 1.0, prior, prior ? theta : nullptr, 0.0, g_out, st);
+}
+
+extern "C" int vt_glm_hvp(const double* X, int64_t ldx, const double* d, const double* prior,
+                          double prior_scalar, const double* v, int64_t N, int D, double* out, void* ws,
+                          size_t ws_bytes, void* stream) {
+    VT_ROWS_PROLOGUE
+    if (!d || !v || !out) return VT_ERR_BAD_ARG;
+    int P = 0;
+    if (N > 0) {
+        RowArgs a{X, ldx, N, D, v, nullptr, nullptr, nullptr, d, 1.0, 0, nullptr, nullptr, nullptr, (double*)ws};
+        P = run_rows<OP_HVP>(a, st);
+        if (P < 0) return P;
+    }
+    bool has_prior = prior != nullptr || prior_scalar != 0.0;
+    return finalize((const double*)ws, D, P, D, 0, 1.0, prior, has_prior ? v : nullptr, prior_scalar, out, st);
+}
+
+extern "C" int vt_gemv_t(const double* X, int64_t ldx, const double* u, int64_t N, int D, double* out,
+                         void* ws, size_t ws_bytes, void* stream) {
+    VT_ROWS_PROLOGUE
+    if (!u || !out) return VT_ERR_BAD_ARG;
+    int P = 0;
+    if (N > 0) {
+        RowArgs a{X, ldx, N, D, nullptr, nullptr, nullptr, nullptr, u, 1.0, 0, nullptr, nullptr, nullptr, (double*)ws};
+        P = run_rows<OP_GEMVT>(a, st);
+        if (P < 0) return P;
+    }
+    return finalize((const double*)ws, D, P, D, 0, 1.0, nullptr, nullptr, 0.0, out, st);
+}
+
+extern "C" int vt_gemv(const double* X, int64_t ldx, const double* v, int64_t N, int D, double* out,
+                       void* ws, size_t ws_bytes, void* stream) {
+    VT_ROWS_PROLOGUE
+    if (!v || !out) return VT_ERR_BAD_ARG;
+    if (N == 0) return VT_OK;
+    RowArgs a{X, ldx, N, D, v, nullptr, nullptr, nullptr, nullptr, 1.0, 0, out, nullptr, nullptr, (double*)ws};
+    int P = run_rows<OP_GEMV>(a, st);
+    return P < 0 ? P : VT_OK;
+}
+
+extern "C" int vt_glm_value(int family, const double* X, int64_t ldx, const double* theta, const double* y,
+                            const double* w, const double* offset, double scale, int64_t N, int D,
+                            double* value_out, void* ws, size_t ws_bytes, void* stream) {
+    VT_ROWS_PROLOGUE
+    if (!theta || !y || !w || !value_out) return VT_ERR_BAD_ARG;
+    int P = 0;
+    if (N > 0) {
+        RowArgs a{X, ldx, N, D, theta, y, w, offset, nullptr, scale, family, nullptr, nullptr, nullptr, (double*)ws};
+        P = run_rows<OP_VALUE>(a, st);
+        if (P < 0) return P;
+    }
+    // value = scale * sum_n w_n ell_n   (the prior term is added by the caller)
+    return finalize((const double*)ws, D, P, 1, D, scale, nullptr, nullptr, 0.0, value_out, st);
+}

@@ -1,0 +1,102 @@
+"""Host wrappers over the dense device solvers (K4/K5): Cholesky factor object."""
+import numpy as np
+import torch
+
+from . import _lib, device as dev
+
+
+class DeviceCholesky:
+    """H = L L^T on the device.  Mirrors what ``scipy.linalg.cho_factor`` /
+    ``cho_solve`` give the reference (vittles/solver_lib.py:26-29)."""
+
+    def __init__(self, L, pack=None, info=None):
+        self.L = L                  # (D, D) CUDA fp64, lower triangle valid
+        self.D = L.shape[0]
+        self._pack = pack           # MFMA TRSM operand images (lazy)
+        self._info = info           # device int32: LAPACK-style potrf info (None = known good)
+
+    def raise_if_failed(self):
+        """Read potrf's info (one host sync) and raise like SciPy does
+        (``scipy/linalg/_decomp_cholesky.py:37-39``)."""
+        if self._info is not None:
+            k = int(self._info.item())
+            self._info = None
+            if k > 0:
+                raise np.linalg.LinAlgError(
+                    "%d-th leading minor of the array is not positive definite" % k)
+
+    # -- construction -----------------------------------------------------
+    @classmethod
+    def factor(cls, H, check=True):
+        """Factor a (D, D) CUDA tensor (not modified).  Raises LinAlgError like SciPy
+        when H is not positive definite; with ``check=False`` the test is deferred to
+        ``raise_if_failed()`` so that dependent kernels can be queued without a sync."""
+        lib = dev.require_gpu()
+        D = H.shape[0]
+        if H.ndim != 2 or H.shape[1] != D:
+            raise ValueError('Input array needs to be a square matrix.')
+        L = H.detach().clone().contiguous()
+        info = torch.zeros(1, dtype=torch.int32, device=L.device)
+        _lib.check(lib.vt_potrf(L.data_ptr(), D, D, info.data_ptr(), 0, 0, dev.stream_ptr()), "vt_potrf")
+        chol = cls(L, info=info)
+        if check:
+            chol.raise_if_failed()
+        return chol
+
+    @classmethod
+    def from_scipy(cls, h_chol, device=None):
+        """Adopt a factor made by ``scipy.linalg.cho_factor`` -> ``(c, lower)``
+        (vittles/solver_lib.py:15-18: if given, ``h`` is ignored)."""
+        c, lower = h_chol
+        c = dev.to_device(c, device)
+        L = c if lower else c.t()
+        return cls(torch.tril(L).contiguous())
+
+    # -- solves -------------------------------------------------------------
+    def solve(self, v):
+        """H^{-1} v for v of shape (D,) or (D, K) (CUDA tensor); returns a new tensor."""
+        lib = dev.require_gpu()
+        if v.shape[0] != self.D:
+            raise ValueError("incompatible dimensions: factor is %dx%d, b has %d rows"
+                             % (self.D, self.D, v.shape[0]))
+        if v.ndim == 1:
+            x = v.detach().clone().contiguous()
+            _lib.check(lib.vt_potrs(self.L.data_ptr(), self.D, self.D, x.data_ptr(), 1, self.D, 1,
+                                    dev.stream_ptr()), "vt_potrs")
+            return x
+        K = v.shape[1]
+        if self.D <= _lib.SMALL_D_MAX and K >= 64:
+            # MFMA TRSM wants right-hand sides as rows: (K, D) row-major.
+            rows = v.detach().t().contiguous()
+            out = self.solve_rows(rows)
+            return out.t()          # (D, K), F-contiguous like cho_solve's result
+        x = v.detach().clone().contiguous()
+        _lib.check(lib.vt_potrs(self.L.data_ptr(), self.D, self.D, x.data_ptr(), K, 1, K,
+                                dev.stream_ptr()), "vt_potrs")
+        return x
+
+    def pack(self):
+        if self._pack is None:
+            lib = dev.require_gpu()
+            nbytes = lib.vt_trsm_pack_bytes(self.D)
+            if nbytes == 0:
+                raise _lib.VittlesHipError("MFMA TRSM pack supports D <= %d" % _lib.SMALL_D_MAX)
+            self._pack = torch.empty(nbytes // 8, dtype=torch.float64, device=self.L.device)
+            _lib.check(lib.vt_trsm_pack(self.L.data_ptr(), self.D, self.D, self._pack.data_ptr(),
+                                        dev.stream_ptr()), "vt_trsm_pack")
+        return self._pack
+
+    def solve_rows(self, B, rowscale=None, alpha=1.0, out=None):
+        """out[n, :] = alpha * rowscale[n] * H^{-1} B[n, :]  for a row-major (N, D) B."""
+        lib = dev.require_gpu()
+        N, D = B.shape
+        if D != self.D:
+            raise ValueError("B must have %d columns" % self.D)
+        if B.stride(1) != 1:
+            B = B.contiguous()
+        if out is None:
+            out = torch.empty((N, D), dtype=torch.float64, device=B.device)
+        _lib.check(lib.vt_trsm_rows(self.pack().data_ptr(), D, B.data_ptr(), B.stride(0),
+                                    dev.ptr(rowscale), float(alpha), N, out.data_ptr(), out.stride(0),
+                                    dev.stream_ptr()), "vt_trsm_rows")
+        return out

@@ -1,0 +1,109 @@
+"""Host wrappers over the row-streaming kernels (vt_rows.hip): K0, K3, K6, K9, value."""
+import torch
+
+from . import _lib, device as dev
+
+_ws_cache = {}
+
+
+def _workspace(D, device):
+    lib = dev.require_gpu()
+    nbytes = lib.vt_rows_workspace_bytes(int(D))
+    key = (device.index, nbytes)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _rowmajor(A):
+    return A if A.stride(1) == 1 else A.contiguous()
+
+
+def gemv_t(A, u):
+    """out (D,) = A^T u for a row-major (N, D) CUDA tensor A (K9)."""
+    lib = dev.require_gpu()
+    A = _rowmajor(A)
+    N, D = A.shape
+    u = u.contiguous()
+    out = torch.empty(D, dtype=torch.float64, device=A.device)
+    ws = _workspace(D, A.device)
+    _lib.check(lib.vt_gemv_t(A.data_ptr(), A.stride(0), u.data_ptr(), N, D, out.data_ptr(),
+                             ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_gemv_t")
+    return out
+
+
+def gemv(A, v):
+    """out (N,) = A v for a row-major (N, D) CUDA tensor A."""
+    lib = dev.require_gpu()
+    A = _rowmajor(A)
+    N, D = A.shape
+    v = v.contiguous()
+    out = torch.empty(N, dtype=torch.float64, device=A.device)
+    ws = _workspace(D, A.device)
+    _lib.check(lib.vt_gemv(A.data_ptr(), A.stride(0), v.data_ptr(), N, D, out.data_ptr(),
+                           ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_gemv")
+    return out
+
+
+def glm_link(obj, theta, w, want_z=False):
+    """K0: per-row (z,) r, d for a WeightedGLMObjective."""
+    lib = dev.require_gpu()
+    theta = dev.to_device(theta, obj.device).contiguous()
+    w = dev.to_device(w, obj.device).contiguous()
+    z = torch.empty(obj.N, dtype=torch.float64, device=obj.device) if want_z else None
+    r = torch.empty(obj.N, dtype=torch.float64, device=obj.device)
+    d = torch.empty(obj.N, dtype=torch.float64, device=obj.device)
+    ws = _workspace(obj.D, obj.device)
+    _lib.check(lib.vt_glm_link(_lib.FAMILY[obj.family], obj.X.data_ptr(), obj.X.stride(0), theta.data_ptr(),
+                               obj.y.data_ptr(), w.data_ptr(), dev.ptr(obj.offset), obj.scale, obj.N, obj.D,
+                               dev.ptr(z), r.data_ptr(), d.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                               dev.stream_ptr()), "vt_glm_link")
+    return z, r, d
+
+
+def glm_grad(obj, theta, w, prior=None):
+    """K3: g = X^T (w r) (+ prior theta); also returns r, d."""
+    lib = dev.require_gpu()
+    theta = dev.to_device(theta, obj.device).contiguous()
+    w = dev.to_device(w, obj.device).contiguous()
+    g = torch.empty(obj.D, dtype=torch.float64, device=obj.device)
+    r = torch.empty(obj.N, dtype=torch.float64, device=obj.device)
+    d = torch.empty(obj.N, dtype=torch.float64, device=obj.device)
+    ws = _workspace(obj.D, obj.device)
+    _lib.check(lib.vt_glm_grad(_lib.FAMILY[obj.family], obj.X.data_ptr(), obj.X.stride(0), theta.data_ptr(),
+                               obj.y.data_ptr(), w.data_ptr(), dev.ptr(obj.offset), obj.scale, dev.ptr(prior),
+                               obj.N, obj.D, g.data_ptr(), r.data_ptr(), d.data_ptr(), ws.data_ptr(),
+                               ws.numel() * 8, dev.stream_ptr()), "vt_glm_grad")
+    return g, r, d
+
+
+def glm_hvp(X, d, v, prior=None, prior_scalar=0.0, out=None):
+    """K6: out = X^T (d .* (X v)) + prior .* v."""
+    lib = dev.require_gpu()
+    N, D = X.shape
+    if out is None:
+        out = torch.empty(D, dtype=torch.float64, device=X.device)
+    ws = _workspace(D, X.device)
+    _lib.check(lib.vt_glm_hvp(X.data_ptr(), X.stride(0), d.data_ptr(), dev.ptr(prior), float(prior_scalar),
+                              v.data_ptr(), N, D, out.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                              dev.stream_ptr()), "vt_glm_hvp")
+    return out
+
+
+def glm_value(obj, theta, w):
+    """Objective value f(theta, w) as a Python float."""
+    lib = dev.require_gpu()
+    theta = dev.to_device(theta, obj.device).contiguous()
+    w = dev.to_device(w, obj.device).contiguous()
+    val = torch.empty(1, dtype=torch.float64, device=obj.device)
+    ws = _workspace(obj.D, obj.device)
+    _lib.check(lib.vt_glm_value(_lib.FAMILY[obj.family], obj.X.data_ptr(), obj.X.stride(0), theta.data_ptr(),
+                                obj.y.data_ptr(), w.data_ptr(), dev.ptr(obj.offset), obj.scale, obj.N, obj.D,
+                                val.data_ptr(), ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_glm_value")
+    obj._all_reduce(val)
+    total = float(val.item())
+    if obj.prior is not None:
+        total += 0.5 * float((obj.prior * theta * theta).sum().item())
+    return total

@@ -1,0 +1,223 @@
+"""Drop-in for the linear-approximation classes of ``vittles/sensitivity_lib.py``
+(reference: /root/reference/vittles/sensitivity_lib.py:85-429), computing on the
+MI355X.  Same constructor arguments, same methods, same error messages, same
+sign / shape conventions:  ``S = -H^{-1} jac0`` with shape (len(opt), len(hyper)).
+
+Differences that the absence of autograd forces:
+  * ``objective_fun`` must be a ``RegisteredObjective`` (closed-form derivatives in
+    HIP kernels) unless BOTH ``hessian_at_opt`` and ``cross_hess_at_opt`` are given
+    and ``validate_optimum`` is False -- then any callable is accepted, exactly the
+    inputs the reference would not differentiate either.
+  * Results have the container type of ``opt_par_value``: numpy in -> numpy out
+    (``get_dopt_dhyper()`` is then F-contiguous (D, N) as SciPy's cho_solve returns
+    it), CUDA tensor in -> CUDA tensors out (a transposed view of the row-major
+    (N, D) device buffer: no copy, stays sharded like X).
+"""
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+from . import device as dev
+from . import solver_lib
+from .objectives import RegisteredObjective, LazyCrossHessian
+
+
+def _len(x):
+    return x.shape[0] if hasattr(x, "shape") else len(x)
+
+
+def _norm(x):
+    if isinstance(x, torch.Tensor):
+        return float(torch.linalg.vector_norm(x).item())
+    return float(np.linalg.norm(x))
+
+
+class EstimatingEquationLinearApproximation:
+    """Reference: sensitivity_lib.py:85-254."""
+
+    def __init__(self, estimating_equation, input_val0, hyper_val0, hess_solver,
+                 validate_solution=False, estimating_equation_jac0=None,
+                 hyper_par_estimating_equation=None, solution_tol=1e-8):
+        self._estimating_equation = estimating_equation
+        if hyper_par_estimating_equation is None:
+            self._hyper_par_estimating_equation = self._estimating_equation
+        else:
+            self._hyper_par_estimating_equation = hyper_par_estimating_equation
+        # The reference builds autograd.jacobian(hyper_ee, argnum=1) here (:180-181);
+        # a registered estimating equation carries that Jacobian itself.
+        self._hyper_ee_fun_jac = getattr(self._hyper_par_estimating_equation, "jacobian_hyper", None)
+        self._hess_solver = hess_solver
+        self._solution_tol = solution_tol
+        self.set_location(input_val0, hyper_val0, estimating_equation_jac0,
+                          validate_solution=validate_solution, solution_tol=solution_tol)
+
+    def set_location(self, input_val0, hyper_val0, estimating_equation_jac0,
+                     validate_solution=True, solution_tol=None):
+        # Reference: sensitivity_lib.py:192-226 (same order: copies, check, jac0, shape, solve).
+        self._input_val0 = deepcopy(input_val0)
+        self._hyper_val0 = deepcopy(hyper_val0)
+        self._as_torch = isinstance(input_val0, torch.Tensor)
+
+        if validate_solution:
+            if solution_tol is None:
+                solution_tol = self._solution_tol
+            if self._estimating_equation is None:
+                raise NotImplementedError(
+                    'validate_optimum needs the gradient of the objective: pass a RegisteredObjective '
+                    '(autograd is not part of this build).')
+            ee_val = self._estimating_equation(self._input_val0, self._hyper_val0)
+            ee_norm = _norm(ee_val)
+            if ee_norm > solution_tol:
+                err_msg = \
+                    'The estimating equation is not zero at the proposed  ' + \
+                    'values.  ||ee|| = {} > {} = solution_tol'.format(
+                        ee_norm, solution_tol)
+                raise ValueError(err_msg)
+
+        if estimating_equation_jac0 is None:
+            if self._hyper_ee_fun_jac is None:
+                raise NotImplementedError(
+                    'No cross-Hessian: pass ``cross_hess_at_opt`` or a RegisteredObjective '
+                    '(autograd is not part of this build).')
+            self._estimating_equation_jac0 = self._hyper_ee_fun_jac(self._input_val0, self._hyper_val0)
+        else:
+            self._estimating_equation_jac0 = estimating_equation_jac0
+        if tuple(self._estimating_equation_jac0.shape) != \
+                (_len(self._input_val0), _len(self._hyper_val0)):
+            raise ValueError('``_estimating_equation_jac0`` is the wrong shape.')
+
+        jac0 = self._estimating_equation_jac0
+        chol = getattr(self._hess_solver, "cholesky", None)
+        self._sens_rows = None      # (N, D) row-major CUDA tensor when computed on the fast path
+        self._sens_host = None
+        if isinstance(jac0, LazyCrossHessian):
+            if chol is not None and chol.D <= 128:
+                # K2 + K5 fused: S[n, :] = -r_n H^{-1} x_n, jac0 never materialised.
+                self._sens_rows = chol.solve_rows(jac0.X, rowscale=jac0.r, alpha=-1.0)
+            else:
+                self._sens_rows = (-1 * self._hess_solver(jac0.materialize())).t().contiguous()
+        elif chol is not None and chol.D <= 128 and _len(self._hyper_val0) >= 64:
+            rows = dev.to_device(jac0, chol.L.device).t().contiguous()
+            self._sens_rows = chol.solve_rows(rows, alpha=-1.0)
+        else:
+            sens = -1 * self._hess_solver(jac0)
+            self._sens_rows = dev.to_device(sens).t().contiguous()
+
+    @property
+    def _sens_mat(self):
+        """(D, N) sensitivity matrix in the caller's container type."""
+        if self._as_torch:
+            return self._sens_rows.t()
+        if self._sens_host is None:
+            self._sens_host = self._sens_rows.cpu().numpy().T   # F-contiguous (D, N)
+        return self._sens_host
+
+    def get_dinput_dhyper(self):
+        return self._sens_mat
+
+    def hess_solver(self):
+        return self._hess_solver
+
+    def predict_input_par_from_hyper_par(self, new_hyper_par_value):
+        """``input_val0 + sens_mat @ (new_hyper - hyper_val0)`` (reference :236-247),
+        as one streaming pass over the device-resident S."""
+        from . import rows
+        devc = self._sens_rows.device
+        delta = dev.to_device(new_hyper_par_value, devc) - dev.to_device(self._hyper_val0, devc)
+        if delta.ndim != 1 or delta.shape[0] != self._sens_rows.shape[0]:
+            raise ValueError('new_hyper_par_value has the wrong shape.')
+        out = rows.gemv_t(self._sens_rows, delta) + dev.to_device(self._input_val0, devc)
+        return dev.like_input(out, self._input_val0)
+
+    def get_input_par_function(self):
+        raise NotImplementedError(
+            'get_input_par_function builds an autograd primitive in the reference '
+            '(sensitivity_lib.py:18-82); autograd is out of scope for this build.')
+
+
+class HyperparameterSensitivityLinearApproximation(EstimatingEquationLinearApproximation):
+    """Reference: sensitivity_lib.py:258-429."""
+
+    def __init__(self, objective_fun, opt_par_value, hyper_par_value,
+                 validate_optimum=False, hessian_at_opt=None, cross_hess_at_opt=None,
+                 hyper_par_objective_fun=None, grad_tol=1e-8):
+        self._objective_fun = objective_fun
+        registered = isinstance(objective_fun, RegisteredObjective)
+        if not registered and not callable(objective_fun):
+            raise TypeError('objective_fun must be callable.')
+        if not registered and (hessian_at_opt is None or cross_hess_at_opt is None):
+            raise NotImplementedError(
+                'objective_fun is not a RegisteredObjective: pass both ``hessian_at_opt`` and '
+                '``cross_hess_at_opt`` (autograd is not part of this build).')
+        obj_fun_grad = _GradOf(objective_fun) if registered else None
+
+        if hyper_par_objective_fun is None:
+            hyper_par_objective_fun = self._objective_fun
+        hyper_obj_fun_grad = _GradOf(hyper_par_objective_fun) \
+            if isinstance(hyper_par_objective_fun, RegisteredObjective) else None
+
+        hess_solver = self._get_hessian_solver(opt_par_value, hyper_par_value, hessian_at_opt)
+
+        EstimatingEquationLinearApproximation.__init__(
+            self,
+            estimating_equation=obj_fun_grad,
+            input_val0=opt_par_value,
+            hyper_val0=hyper_par_value,
+            hess_solver=hess_solver,
+            validate_solution=validate_optimum,
+            estimating_equation_jac0=cross_hess_at_opt,
+            hyper_par_estimating_equation=hyper_obj_fun_grad,
+            solution_tol=grad_tol)
+
+    def _get_hessian_solver(self, opt_par_value, hyper_par_value, hessian_at_opt):
+        # Reference: sensitivity_lib.py:376-390.
+        if hessian_at_opt is None:
+            self._hess0_dev = self._objective_fun.hessian(
+                dev.to_device(opt_par_value), dev.to_device(hyper_par_value))
+            self._hess0 = dev.like_input(self._hess0_dev, opt_par_value)
+        else:
+            self._hess0 = hessian_at_opt
+        if tuple(self._hess0.shape) != (_len(opt_par_value), _len(opt_par_value)):
+            raise ValueError('``hessian_at_opt`` is the wrong shape.')
+        return solver_lib.get_cholesky_solver(self._hess0)
+
+    def set_base_values(self, opt_par_value, hyper_par_value,
+                        hessian_at_opt, cross_hess_at_opt,
+                        validate_optimum=True, grad_tol=None):
+        # Reference: sensitivity_lib.py:392-405 computes a new solver and then drops it
+        # (the stale-solver bug noted in SURVEY.md section 5); here the new solver is used.
+        self._hess_solver = self._get_hessian_solver(opt_par_value, hyper_par_value, hessian_at_opt)
+        EstimatingEquationLinearApproximation.set_location(
+            self, input_val0=opt_par_value, hyper_val0=hyper_par_value,
+            estimating_equation_jac0=cross_hess_at_opt,
+            validate_solution=validate_optimum, solution_tol=grad_tol)
+
+    def get_dopt_dhyper(self):
+        return super().get_dinput_dhyper()
+
+    def get_hessian_at_opt(self):
+        return self._hess0
+
+    def predict_opt_par_from_hyper_par(self, new_hyper_par_value):
+        return super().predict_input_par_from_hyper_par(new_hyper_par_value)
+
+    def get_opt_par_function(self):
+        return super().get_input_par_function()
+
+
+class _GradOf:
+    """``autograd.grad(objective, argnum=0)`` for a registered objective, carrying the
+    Jacobian w.r.t. the hyper-parameter that the reference builds with
+    ``autograd.jacobian(..., argnum=1)`` (sensitivity_lib.py:180-181)."""
+
+    def __init__(self, objective):
+        self._obj = objective
+
+    def __call__(self, opt_par, hyper_par):
+        obj = self._obj
+        g = obj.grad(dev.to_device(opt_par), dev.to_device(hyper_par))
+        return dev.like_input(g, opt_par)
+
+    def jacobian_hyper(self, opt_par, hyper_par):
+        return self._obj.cross_hessian(dev.to_device(opt_par), dev.to_device(hyper_par))
