@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvittles_hip.so")
+LIB_PATH = os.environ.get("VITTLES_HIP_LIB", os.path.join(_HERE, "libvittles_hip.so"))  # env: dev A/B builds
 
 c_double_p = ctypes.c_void_p  # device pointers travel as integers
 c_i64 = ctypes.c_int64

@@ -240,17 +240,20 @@ __device__ __forceinline__ void trsm_product(TrsmState<NB, KL, LASTPERM>& st) {
     if constexpr (IDX < S::M) {
         if constexpr (IDX + 1 < S::M) {
             constexpr int img = S::image(IDX + 1);
+            constexpr int nks = S::ks(S::src(IDX + 1));
 #pragma unroll
-            for (int s = 0; s < S::ks(S::src(IDX + 1)); ++s) st.nxt[s] = st.lds[(img * 4 + s) * 64 + st.lane];
+            for (int s = 0; s < nks; ++s) st.nxt[s] = st.lds[(img * 4 + s) * 64 + st.lane];
         }
         __builtin_amdgcn_sched_barrier(0);
         constexpr int i = S::src(IDX), j = S::row(IDX);
-        if constexpr (S::first(IDX)) st.acc = (f64x4){0.0, 0.0, 0.0, 0.0};
+        constexpr int cks = S::ks(i);
+        constexpr bool is_first = S::first(IDX), is_last = S::last(IDX), is_bwd = S::bwd(IDX);
+        if constexpr (is_first) st.acc = (f64x4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < S::ks(i); ++s) st.acc = mfma_f64(st.cur[s], st.V[i][s], st.acc);
-        if constexpr (S::last(IDX)) {
+        for (int s = 0; s < cks; ++s) st.acc = mfma_f64(st.cur[s], st.V[i][s], st.acc);
+        if constexpr (is_last) {
             st.V[j] = st.acc;
-            if constexpr (S::bwd(IDX)) {
+            if constexpr (is_bwd) {
                 if (st.store) {
                     if constexpr (S::permuted(j)) {
                         *(f64x2u*)(st.orow + 16 * j + 4 * st.q) = (f64x2u){st.acc[0], st.acc[1]};
@@ -345,8 +348,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
         load_group(grp + W < ngroups ? grp + W : grp);
         {
             constexpr int img = S::image(0);
+            constexpr int nks = S::ks(S::src(0));
 #pragma unroll
-            for (int s = 0; s < S::ks(S::src(0)); ++s) st.cur[s] = lds[(img * 4 + s) * 64 + lane];
+            for (int s = 0; s < nks; ++s) st.cur[s] = lds[(img * 4 + s) * 64 + lane];
         }
         trsm_product<0, NB, KL, LASTPERM>(st);
     }

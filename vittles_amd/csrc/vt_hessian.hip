@@ -34,6 +34,7 @@ struct HessArgs {
     double* d_out;
     double* part;       // [gridDim.x][L] partial slabs, L = NBT*256 + NB*16
     double* wave_part;  // [gridDim.x][4][NBT*256] per-wave slabs
+    double* sink;       // 1024 doubles nobody reads
 };
 
 // Loads are UNCONDITIONAL with clamped row / column indices (a per-element
@@ -41,113 +42,200 @@ struct HessArgs {
 // out-of-range rows re-read row N-1 and are neutralised by d_n = 0, out-of-range
 // columns re-read column D-1 and land in padded rows/columns that are never stored.
 template <int NB>
-__device__ __forceinline__ void load_step(const HessArgs& a, int64_t step, int q, int c, double (&x)[NB]) {
+struct StepData {
+    double x[NB];
+    double y, w, off;
+};
+
+template <int NB, bool HAS_OFF>
+__device__ __forceinline__ void load_step(const HessArgs& a, int64_t step, int q, int c, StepData<NB>& d) {
     int64_t n = step * 4 + q;
     n = n < a.N ? n : a.N - 1;
+#ifdef VT_ABLATE_LOAD
+    n = q;   // dev ablation: always the same 4 rows (L1 hits)
+#endif
     const double* xr = a.X + n * a.ldx;
     const int clast = min(16 * (NB - 1) + c, a.D - 1);
 #pragma unroll
-    for (int b = 0; b < NB - 1; ++b) x[b] = xr[16 * b + c];
-    x[NB - 1] = xr[clast];
+    for (int b = 0; b < NB - 1; ++b) d.x[b] = xr[16 * b + c];
+    d.x[NB - 1] = xr[clast];
+    // per-row scalars ride in the same prefetch slot: loading them at the point of
+    // use exposes a full HBM miss in every k-step.
+    d.y = a.y[n];
+    d.w = a.w[n];
+    d.off = HAS_OFF ? a.offset[n] : 0.0;
 }
 
-template <int NB, int FAM, bool HAS_OFF>
-__global__ __launch_bounds__(256) void k_glm_hess_small(HessArgs a) {
+// One wave's share of the work: HALF selects which blocks of the triangle it owns
+// (blocks with (tri index & 1) == HALF).  fp64 MFMA only reaches its issue rate
+// with >= 2 waves per SIMD (one wave alone gets ~45 % of peak on gfx950, measured:
+// tools/micro/mfma_f64_rate.hip), and one wave cannot hold the whole triangle in
+// the 256 registers it gets at that occupancy -- so waves w and w+4 of a 512-thread
+// workgroup stream the SAME rows (second reader hits L1/L2) and split the blocks.
+template <int NB, int FAM, bool HAS_OFF, int HALF>
+__device__ __forceinline__ void hess_small_body(const HessArgs& a, double* gl) {
     constexpr int NBT = NB * (NB + 1) / 2;
-    constexpr int L = NBT * 256 + NB * 16;
-    __shared__ double gl[4 * NB * 16];
+    constexpr int NH = (NBT + 1 - HALF) / 2;   // blocks owned by this half
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int pair = (threadIdx.x >> 6) & 3;
     const int q = lane >> 4, c = lane & 15;
     const int64_t nsteps = (a.N + 3) >> 2;
     const int64_t W = (int64_t)gridDim.x * 4;
-    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + pair;
 
-    double th[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) th[b] = (16 * b + c < a.D) ? a.theta[16 * b + c] : 0.0;
+    // theta lives in LDS (zero padded): 7 broadcast ds_reads per k-step instead of 14
+    // long-lived VGPRs -- the register budget at 2 waves/SIMD is what limits NB.
+    const double* th = gl + 4 * NB * 16;
 
-    f64x4 acc[NBT];
+    f64x4 acc[NH > 0 ? NH : 1];
 #pragma unroll
-    for (int i = 0; i < NBT; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < NH; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
     double gacc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) gacc[b] = 0.0;
 
-    auto compute = [&](int64_t step, const double (&x)[NB]) {
+    // Software pipeline inside each wave: the link for step s+1 (row dot, 4 shuffle
+    // rounds, exp, divide: a long dependent VALU/LDS chain) is issued in the same
+    // scheduling region as the MFMAs of step s, so it fills the 64-cycle gaps between
+    // MFMAs instead of idling the matrix pipe (measured: with link and MFMAs in
+    // separate phases the two waves of a SIMD run in lockstep and the pipe is 46 % busy).
+    struct Link { double dw, gwt; };
+    auto link = [&](int64_t step, const StepData<NB>& sd) -> Link {
+        const double (&x)[NB] = sd.x;
         int64_t n = step * 4 + q;
         bool rowok = (step < nsteps) && (n < a.N);
         double p = 0.0;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) p = fma(x[b], th[b], p);
+        for (int b = 0; b < NB; ++b) p = fma(x[b], th[16 * b + c], p);
         double z = vt_sum16(p);
-        int64_t nc = n < a.N ? n : a.N - 1;
-        double yv = a.y[nc], wv = a.w[nc];
-        if (HAS_OFF) z += a.offset[nc];
+        double yv = sd.y, wv = sd.w;
+        if (HAS_OFF) z += sd.off;
         double l1, l2;
         vt_link(FAM, z, yv, l1, l2);
         double rr = a.scale * l1;
-        double dw = rowok ? a.scale * wv * l2 : 0.0;
-        double gwt = rowok ? wv * rr : 0.0;
-        if (rowok && c == 0) {
-            if (a.r_out) a.r_out[n] = rr;
-            if (a.d_out) a.d_out[n] = dw;
+        Link lk;
+        lk.dw = rowok ? a.scale * wv * l2 : 0.0;
+        lk.gwt = rowok ? wv * rr : 0.0;
+        if constexpr (HALF == 0) {
+            // branch-free per-row outputs: lanes with nothing to store write to a sink
+            // (any control flow here makes hipcc drain vmcnt(0) every phase).
+            bool st = rowok && c == 0;
+            double* rp = (st && a.r_out) ? a.r_out + n : a.sink + threadIdx.x;
+            double* dp = (st && a.d_out) ? a.d_out + n : a.sink + 512 + threadIdx.x;
+            *rp = rr;
+            *dp = lk.dw;
         }
-        double bb[NB];
+        return lk;
+    };
+    auto mfmas = [&](const StepData<NB>& sd, const Link& lk) {
+        const double (&x)[NB] = sd.x;
+        if constexpr (HALF == 1) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            gacc[b] = fma(gwt, x[b], gacc[b]);
-            bb[b] = dw * x[b];
+            for (int b = 0; b < NB; ++b) gacc[b] = fma(lk.gwt, x[b], gacc[b]);
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
+        for (int j = 0; j < NB; ++j) {
+            double bj = lk.dw * x[j];
 #pragma unroll
-            for (int j = 0; j <= i; ++j) acc[vt_tri(i, j)] = mfma_f64(x[i], bb[j], acc[vt_tri(i, j)]);
+            for (int i = j; i < NB; ++i)
+                if ((vt_tri(i, j) & 1) == HALF) {
+#ifdef VT_ABLATE_MFMA
+                    acc[vt_tri(i, j) >> 1][0] += x[i] * bj;   // dev ablation: no MFMA
+#else
+                    acc[vt_tri(i, j) >> 1] = mfma_f64(x[i], bj, acc[vt_tri(i, j) >> 1]);
+#endif
+                }
+        }
     };
 
-    // 3-deep register prefetch ring over this wave's interleaved k-steps.
-    double x0[NB], x1[NB], x2[NB];
+    // Pin the interleave: after every MFMA a handful of the link's VALU / LDS ops.
+    auto interleave = [&]() {
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // 6 VALU
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS read (bpermute pair / theta)
+        }
+    };
+
+    // 4-deep register ring over this wave pair's interleaved k-steps: in phase k the
+    // link runs on buffer k+1 (loaded 3 phases ago), the MFMAs on buffer k, and buffer
+    // k is then refilled with step k+4.
+    StepData<NB> x0, x1, x2, x3;
     int64_t s = gw;
-    load_step<NB>(a, s, q, c, x0);
-    load_step<NB>(a, s + W, q, c, x1);
-    load_step<NB>(a, s + 2 * W, q, c, x2);
-    for (; s < nsteps; s += 3 * W) {
-        compute(s, x0);
-        load_step<NB>(a, s + 3 * W, q, c, x0);
-        compute(s + W, x1);
-        load_step<NB>(a, s + 4 * W, q, c, x1);
-        compute(s + 2 * W, x2);
-        load_step<NB>(a, s + 5 * W, q, c, x2);
+    load_step<NB, HAS_OFF>(a, s, q, c, x0);
+    load_step<NB, HAS_OFF>(a, s + W, q, c, x1);
+    load_step<NB, HAS_OFF>(a, s + 2 * W, q, c, x2);
+    load_step<NB, HAS_OFF>(a, s + 3 * W, q, c, x3);
+    Link l0 = link(s, x0), l1, l2, l3;
+    for (; s < nsteps; s += 4 * W) {
+        mfmas(x0, l0);
+        l1 = link(s + W, x1);
+        interleave();
+        load_step<NB, HAS_OFF>(a, s + 4 * W, q, c, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(x1, l1);
+        l2 = link(s + 2 * W, x2);
+        interleave();
+        load_step<NB, HAS_OFF>(a, s + 5 * W, q, c, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(x2, l2);
+        l3 = link(s + 3 * W, x3);
+        interleave();
+        load_step<NB, HAS_OFF>(a, s + 6 * W, q, c, x2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(x3, l3);
+        l0 = link(s + 4 * W, x0);
+        interleave();
+        load_step<NB, HAS_OFF>(a, s + 7 * W, q, c, x3);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- gradient: sum the 4 row groups of the wave, then the 4 waves ----------
+    // ---- gradient: sum the 4 row groups of the wave (half 1 only) ---------------
+    if constexpr (HALF == 1) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        double v = gacc[b];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (q == 0) gl[wave * (NB * 16) + 16 * b + c] = v;
+        for (int b = 0; b < NB; ++b) {
+            double v = gacc[b];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (q == 0) gl[pair * (NB * 16) + 16 * b + c] = v;
+        }
     }
 
-    // ---- H accumulators: 4 waves -> 1 -------------------------------------------
-    // The accumulators leave the AGPR file only through GLOBAL stores: a ds_write
-    // (or any VALU op) on them makes hipcc keep all of them in VGPRs for the whole
-    // kernel and spill everything else.  Each wave parks its slab in the workspace
-    // (L2-resident), the workgroup then folds its 4 slabs into one.
-    double* wslab = a.wave_part + (int64_t)blockIdx.x * 4 * (NBT * 256);
-    {
-        double* mine = wslab + wave * (NBT * 256);
+    // ---- H accumulators ------------------------------------------------------------
+    // They leave the register file only through GLOBAL stores: a ds_write (or any VALU
+    // op) on them makes hipcc keep all of them in VGPRs for the whole kernel and spill
+    // everything else.  Each wave parks its blocks in the pair's slab in the workspace
+    // (L2-resident); the workgroup then folds its 4 slabs into one.
+    double* mine = a.wave_part + ((int64_t)blockIdx.x * 4 + pair) * (NBT * 256);
 #pragma unroll
-        for (int i = 0; i < NBT; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mine[(i * 4 + r) * 64 + lane] = acc[i][r];
-    }
+        for (int j = 0; j <= i; ++j)
+            if ((vt_tri(i, j) & 1) == HALF) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[(vt_tri(i, j) * 4 + r) * 64 + lane] = acc[vt_tri(i, j) >> 1][r];
+            }
+}
+
+template <int NB, int FAM, bool HAS_OFF>
+__global__ __launch_bounds__(512) void k_glm_hess_small(HessArgs a) {
+    constexpr int NBT = NB * (NB + 1) / 2;
+    constexpr int L = NBT * 256 + NB * 16;
+    __shared__ double gl[5 * NB * 16];   // 4 gradient slots + theta
+    for (int t = threadIdx.x; t < NB * 16; t += 512) gl[4 * NB * 16 + t] = t < a.D ? a.theta[t] : 0.0;
     __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0)
+        hess_small_body<NB, FAM, HAS_OFF, 0>(a, gl);
+    else
+        hess_small_body<NB, FAM, HAS_OFF, 1>(a, gl);
+    __syncthreads();
+    const double* wslab = a.wave_part + (int64_t)blockIdx.x * 4 * (NBT * 256);
     double* out = a.part + (int64_t)blockIdx.x * L;
-    for (int e = threadIdx.x; e < NBT * 256; e += 256)
+    for (int e = threadIdx.x; e < NBT * 256; e += 512)
         out[e] = (wslab[e] + wslab[NBT * 256 + e]) + (wslab[2 * NBT * 256 + e] + wslab[3 * NBT * 256 + e]);
-    for (int t = threadIdx.x; t < NB * 16; t += 256)
+    for (int t = threadIdx.x; t < NB * 16; t += 512)
         out[NBT * 256 + t] = (gl[t] + gl[NB * 16 + t]) + (gl[2 * NB * 16 + t] + gl[3 * NB * 16 + t]);
 }
 
@@ -219,9 +307,9 @@ inline int hess_grid(int64_t N) {
 template <int NB, int FAM>
 void launch_hess_small2(const HessArgs& a, int grid, hipStream_t st) {
     if (a.offset)
-        hipLaunchKernelGGL((k_glm_hess_small<NB, FAM, true>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_glm_hess_small<NB, FAM, true>), dim3(grid), dim3(512), 0, st, a);
     else
-        hipLaunchKernelGGL((k_glm_hess_small<NB, FAM, false>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_glm_hess_small<NB, FAM, false>), dim3(grid), dim3(512), 0, st, a);
 }
 
 template <int NB>
@@ -238,7 +326,7 @@ void launch_hess_small(const HessArgs& a, int grid, hipStream_t st) {
 extern "C" size_t vt_glm_hessian_workspace_bytes(int64_t N, int D) {
     if (D < 1 || D > VT_SMALL_D_MAX) return 0;
     int NB = (D + 15) / 16;
-    return ((size_t)(num_cu() + kStage2) * slab_len(NB) + (size_t)num_cu() * 4 * (NB * (NB + 1) / 2) * 256) *
+    return ((size_t)(num_cu() + kStage2) * slab_len(NB) + (size_t)num_cu() * 4 * (NB * (NB + 1) / 2) * 256 + 1024) *
            sizeof(double);
 }
 
@@ -257,8 +345,9 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
     double* part = (double*)ws;
     double* part2 = part + (size_t)num_cu() * L;
     double* wave_part = part2 + (size_t)kStage2 * L;
+    double* sink = wave_part + (size_t)num_cu() * 4 * (NB * (NB + 1) / 2) * 256;
 
-    HessArgs a{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, wave_part};
+    HessArgs a{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, wave_part, sink};
     switch (NB) {
         case 1: launch_hess_small<1>(a, grid, st); break;
         case 2: launch_hess_small<2>(a, grid, st); break;
