@@ -119,8 +119,7 @@ def main():
         out = obj.fused(theta, w)           # K0+K1+K3 (+ all-reduce)
         if i is not None:
             ev[i][1].record()
-        chol = DeviceCholesky.factor(out["H"], check=False)   # K4; info checked after the solve is queued
-        chol.pack()
+        chol = DeviceCholesky.factor(out["H"], check=False, pack=True)   # K4 + TRSM pack, one launch
         if i is not None:
             ev[i][2].record()
         chol.solve_rows(X, rowscale=out["r"], alpha=-1.0, out=S)   # K2+K5

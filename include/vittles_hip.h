@@ -104,6 +104,11 @@ int    vt_potrs(const double* L_dev, int ldl, int D,
 size_t vt_trsm_pack_bytes(int D);
 int    vt_trsm_pack(const double* L_dev, int ldl, int D, void* pack_dev, void* stream);
 
+/* K4 + pack in ONE launch (the inverted diagonal blocks are a by-product of the blocked
+ * factorisation): A <- L in place, *info_dev as vt_potrf, pack_dev as vt_trsm_pack.
+ * Replaces: scipy.linalg.cho_factor(h)   vittles/solver_lib.py:26-27 */
+int    vt_potrf_pack(double* A_dev, int lda, int D, int* info_dev, void* pack_dev, void* stream);
+
 /* Out[n,:] = alpha * s_n * H^{-1} B[n,:]   for n < N  (s_n = 1 if rowscale_dev NULL)
  * Replaces: `-1 * self._hess_solver(self._estimating_equation_jac0)`
  *             vittles/sensitivity_lib.py:226  (dpotrs with nrhs = N)

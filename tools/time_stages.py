@@ -31,6 +31,7 @@ for D in Ds:
     out = f()
     H = obj.fused(theta, w)["H"]
     ms = timeit(lambda: DeviceCholesky.factor(H, check=False))
+    print("D=%d potrf+pack fused %.3f ms" % (D, timeit(lambda: DeviceCholesky.factor(H, check=False, pack=True))))
     chol = DeviceCholesky.factor(H)
     def p():
         chol._pack = None

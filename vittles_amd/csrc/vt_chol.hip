@@ -10,42 +10,179 @@ constexpr int kSmallLd = VT_SMALL_D_MAX + 1;  // odd stride: column walks are ba
 
 // ------------------------------------------------------------------ potrf -------
 // One workgroup, matrix resident in LDS (D <= 128: 132 KB of the CU's 160 KB).
-// Right-looking column Cholesky; latency-bound by construction (D^3/3 flops is
-// nothing), so the budget is barriers: 2 per column.
-__global__ __launch_bounds__(512) void k_potrf_small(double* A, int lda, int D, int* info) {
+// Latency-bound by construction (D^3/3 flops is nothing), so the budget is barriers and
+// dependent LDS round trips.  Blocked right-looking Cholesky with 16-wide panels:
+//   (a) wave 0 factors the 16x16 diagonal block AND inverts it entirely in registers
+//       (lane = row; cross-lane traffic is v_readlane with compile-time lane ids, no LDS),
+//   (b) one thread per row below solves its 16-entry panel row against the inverse,
+//   (c) the trailing blocks are updated with v_mfma_f64_16x16x4_f64 straight from LDS.
+// 3 barriers per panel (21 at D = 100) instead of 3 per column (300).  The inverted diagonal
+// blocks are exactly what the TRSM operand pack needs, so the same kernel emits the pack.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__host__ __device__ __forceinline__ int vt_perm(bool permuted, int p) {
+    return permuted ? (4 * (p & 3) + (p >> 2)) : p;
+}
+
+// mode bit 0: factor A in place (else A already holds L);  pack != NULL: also emit the TRSM pack.
+__global__ __launch_bounds__(256) void k_potrf_pack_small(double* A, int lda, int D, int* info, double* pack,
+                                                         int do_factor) {
     __shared__ double a[VT_SMALL_D_MAX * kSmallLd];
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < D * D; idx += 512) {
-        int i = idx / D, j = idx - i * D;
-        if (j <= i) a[i * kSmallLd + j] = A[(int64_t)i * lda + j];
+    __shared__ double linv[8 * 16 * 17];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NB = (D + 15) >> 4, NP = NB * 16, NBT = NB * (NB + 1) / 2;
+    if (tid == 0) s_bad = 0;
+    for (int idx = tid; idx < NP * NP; idx += 256) {
+        int i = idx / NP, j = idx - i * NP;
+        double v = 0.0;
+        if (i < D && j <= i) v = A[(int64_t)i * lda + j];
+        if (i >= D && j == i) v = 1.0;
+        a[i * kSmallLd + j] = v;
     }
     __syncthreads();
-    int bad = 0;
-    for (int k = 0; k < D; ++k) {
-        double akk = a[k * kSmallLd + k];
-        if (!(akk > 0.0)) {  // also catches NaN, as LAPACK's disnan test does
-            bad = k + 1;
-            break;
+    for (int J = 0; J < NB; ++J) {
+        const int o = 16 * J;
+        if (wave == 0) {
+            // ---- (a) diagonal block: factor + invert in registers, lane r = row r ----------
+            const int r = lane & 15;
+            double row[16];
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) row[cc] = a[(o + r) * kSmallLd + o + cc];
+            int bad = 0;
+            double rdiag[16];
+            if (do_factor) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    double akk = readlane_f64(row[k], k);
+                    if (!(akk > 0.0) && bad == 0 && o + k < D) bad = o + k + 1;
+                    double piv = sqrt(akk > 0.0 ? akk : 1.0);
+                    double rp = 1.0 / piv;
+                    rdiag[k] = rp;
+                    double lk = r > k ? row[k] * rp : 0.0;
+                    row[k] = r == k ? piv : lk;
+#pragma unroll
+                    for (int j = k + 1; j < 16; ++j) {
+                        double ljk = readlane_f64(lk, j);
+                        row[j] = fma(-lk, ljk, row[j]);
+                    }
+                }
+                if (lane < 16) {
+#pragma unroll
+                    for (int cc = 0; cc < 16; ++cc) a[(o + r) * kSmallLd + o + cc] = cc <= r ? row[cc] : 0.0;
+                }
+                if (bad && lane == 0) s_bad = bad;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) rdiag[k] = 1.0 / readlane_f64(row[k], k);
+            }
+            // inverse: lane c holds column c of L_JJ^{-1}:  x_i = (delta_ic - sum_{m<i} L[i][m] x_m) / L[i][i]
+            const int c = r;
+            double x[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double sacc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                for (int m = 0; m < i; ++m) sacc = fma(-readlane_f64(row[m], i), x[m], sacc);
+                x[i] = i < c ? 0.0 : sacc * rdiag[i];
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) linv[(J * 16 + i) * 17 + c] = x[i];
+            }
         }
-        double piv = sqrt(akk);
-        double rpiv = 1.0 / piv;
-        __syncthreads();  // everyone has read a[k][k]
-        for (int i = k + 1 + tid; i < D; i += 512) a[i * kSmallLd + k] *= rpiv;
-        if (tid == 0) a[k * kSmallLd + k] = piv;
         __syncthreads();
-        for (int i = k + 1 + (tid >> 5); i < D; i += 16) {
-            double aik = a[i * kSmallLd + k];
-            for (int j = k + 1 + (tid & 31); j <= i; j += 32)
-                a[i * kSmallLd + j] -= aik * a[j * kSmallLd + k];
+        if (s_bad) break;
+        if (do_factor && J + 1 < NB) {
+            // ---- (b) panel: row R of the blocks below:  L[R][o..o+15] = A[R][o..] * Linv^T ----
+            const int R = o + 16 + tid;
+            if (R < NP) {
+                double t[16], u[16];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) t[m] = a[R * kSmallLd + o + m];
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int m = 0; m <= cc; ++m) sacc = fma(t[m], linv[(J * 16 + cc) * 17 + m], sacc);
+                    u[cc] = sacc;
+                }
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) a[R * kSmallLd + o + cc] = u[cc];
+            }
+            __syncthreads();
+            // ---- (c) trailing update  A_ik -= L_iJ L_kJ^T,  J < k <= i, on the MFMA --------
+            const int nb = NB - J - 1;
+            const int nt = nb * (nb + 1) / 2;
+            const int q = lane >> 4, cl = lane & 15;
+            for (int t = wave; t < nt; t += 4) {
+                int bi = 0;
+                while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+                int bk = t - bi * (bi + 1) / 2;
+                const int ri = o + 16 + 16 * bi, rk = o + 16 + 16 * bk;
+                f64x4 cacc;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) cacc[rr] = a[(ri + q + 4 * rr) * kSmallLd + rk + cl];
+#pragma unroll
+                for (int sstep = 0; sstep < 4; ++sstep) {
+                    double av = -a[(ri + cl) * kSmallLd + o + 4 * sstep + q];
+                    double bv = a[(rk + cl) * kSmallLd + o + 4 * sstep + q];
+                    cacc = mfma_f64(av, bv, cacc);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) a[(ri + q + 4 * rr) * kSmallLd + rk + cl] = cacc[rr];
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     __syncthreads();
-    for (int idx = tid; idx < D * D; idx += 512) {
-        int i = idx / D, j = idx - i * D;
-        if (j <= i) A[(int64_t)i * lda + j] = a[i * kSmallLd + j];
+    const int bad = s_bad;
+    if (do_factor) {
+        for (int idx = tid; idx < D * D; idx += 256) {
+            int i = idx / D, j = idx - i * D;
+            if (j <= i) A[(int64_t)i * lda + j] = a[i * kSmallLd + j];
+        }
+        if (tid == 0 && info) *info = bad;
     }
-    if (tid == 0) *info = bad;
+    if (pack == nullptr || bad) return;
+    // ---- TRSM operand pack (see vt_trsm_pack) ---------------------------------------------
+    const bool lastperm = (D & 15) == 0;
+    const int total = 2 * NBT * 256;
+    for (int e = tid; e < total; e += 256) {
+        int PI = e >> 8, sstep = (e >> 6) & 3, ln = e & 63;
+        int q = ln >> 4, rho = ln & 15;
+        bool bwd = PI >= NBT;
+        int t = bwd ? PI - NBT : PI;
+        int hi = 0;
+        while ((hi + 1) * (hi + 2) / 2 <= t) ++hi;
+        int lo = t - hi * (hi + 1) / 2;
+        int j = bwd ? lo : hi, i = bwd ? hi : lo;
+        int row = vt_perm(j < NB - 1 || lastperm, rho);
+        int col = vt_perm(i < NB - 1 || lastperm, 4 * sstep + q);
+        double v;
+        if (!bwd) {
+            if (i == j) {
+                v = linv[(j * 16 + row) * 17 + col];
+            } else {
+                v = 0.0;
+                for (int m = 0; m < 16; ++m)
+                    v -= linv[(j * 16 + row) * 17 + m] * a[(16 * j + m) * kSmallLd + 16 * i + col];
+            }
+        } else {
+            if (i == j) {
+                v = linv[(j * 16 + col) * 17 + row];
+            } else {
+                v = 0.0;
+                for (int m = 0; m < 16; ++m)
+                    v -= linv[(j * 16 + m) * 17 + row] * a[(16 * i + col) * kSmallLd + 16 * j + m];
+            }
+        }
+        pack[e] = v;
+    }
 }
 
 // ------------------------------------------------------------------ potrs -------
@@ -82,84 +219,17 @@ __global__ __launch_bounds__(64) void k_potrs_generic(const double* L, int ldl, 
 }
 
 // -------------------------------------------------------------- TRSM pack -------
-// Logical -> hardware index maps inside a 16-wide block.  A "permuted" (full)
-// block keeps logical index 4q+s at accumulator register s of lane group q, so a
-// lane owns 4 CONSECUTIVE columns (32 contiguous bytes of a row of X / S); the
-// trailing partial block keeps the native MFMA order 4s+q so that its all-zero
-// k-steps can be skipped.
-__host__ __device__ __forceinline__ int vt_perm(bool permuted, int p) {
-    return permuted ? (4 * (p & 3) + (p >> 2)) : p;
-}
-
+// Logical -> hardware index maps inside a 16-wide block (vt_perm).  A "permuted" (full)
+// block keeps logical index 4q+s at accumulator register s of lane group q, so a lane owns
+// 4 CONSECUTIVE columns (32 contiguous bytes of a row of X / S); the trailing partial block
+// keeps the native MFMA order 4s+q so that its all-zero k-steps can be skipped.
+//
 // pack[(PI*4 + s)*64 + lane]: A operand of k-step s for block pair PI.
 //   forward  pair (j,i), i<=j : PI = tri(j,i)        F_jj = Linv_jj,  F_ji = -Linv_jj L_ji
 //   backward pair (j,i), i>=j : PI = NBT + tri(i,j)  B_jj = Linv_jj^T, B_ji = -Linv_jj^T L_ij^T
 // so that   Y_j = sum_{i<=j} F_ji (G_i | Y_i)   and   Z_j = B_jj Y_j + sum_{i>j} B_ji Z_i
 // are pure MFMA accumulations (no divisions, no subtractions in the solve kernel).
-__global__ __launch_bounds__(256) void k_trsm_pack(const double* L, int ldl, int D, double* pack) {
-    __shared__ double l[VT_SMALL_D_MAX * kSmallLd];
-    __shared__ double linv[8 * 16 * 17];
-    const int tid = threadIdx.x;
-    const int NB = (D + 15) >> 4, NP = NB * 16, NBT = NB * (NB + 1) / 2;
-    const bool lastperm = (D & 15) == 0;
-    for (int idx = tid; idx < NP * NP; idx += 256) {
-        int i = idx / NP, j = idx - i * NP;
-        double v = 0.0;
-        if (i < D && j <= i) v = L[(int64_t)i * ldl + j];
-        if (i >= D && j == i) v = 1.0;
-        l[i * kSmallLd + j] = v;
-    }
-    __syncthreads();
-    // Inverse of each 16x16 diagonal block: thread (b, col) solves L_bb x = e_col.
-    if (tid < NB * 16) {
-        int b = tid >> 4, col = tid & 15;
-        double x[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            double s = (i == col) ? 1.0 : 0.0;
-#pragma unroll
-            for (int m = 0; m < 16; ++m)
-                if (m < i) s -= l[(16 * b + i) * kSmallLd + 16 * b + m] * x[m];
-            x[i] = (i < col) ? 0.0 : s / l[(16 * b + i) * kSmallLd + 16 * b + i];
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) linv[(b * 16 + i) * 17 + col] = x[i];
-    }
-    __syncthreads();
-    const int total = 2 * NBT * 256;
-    for (int e = tid; e < total; e += 256) {
-        int PI = e >> 8, s = (e >> 6) & 3, lane = e & 63;
-        int q = lane >> 4, rho = lane & 15;
-        bool bwd = PI >= NBT;
-        int t = bwd ? PI - NBT : PI;
-        int hi = 0;
-        while ((hi + 1) * (hi + 2) / 2 <= t) ++hi;
-        int lo = t - hi * (hi + 1) / 2;
-        // forward: j = hi (row block), i = lo.  backward: j = lo (row block), i = hi.
-        int j = bwd ? lo : hi, i = bwd ? hi : lo;
-        int row = vt_perm(j < NB - 1 || lastperm, rho);
-        int col = vt_perm(i < NB - 1 || lastperm, 4 * s + q);
-        double v;
-        if (!bwd) {
-            if (i == j) {
-                v = linv[(j * 16 + row) * 17 + col];
-            } else {
-                v = 0.0;
-                for (int m = 0; m < 16; ++m)
-                    v -= linv[(j * 16 + row) * 17 + m] * l[(16 * j + m) * kSmallLd + 16 * i + col];
-            }
-        } else {
-            if (i == j) {
-                v = linv[(j * 16 + col) * 17 + row];
-            } else {
-                v = 0.0;
-                for (int m = 0; m < 16; ++m)
-                    v -= linv[(j * 16 + m) * 17 + row] * l[(16 * i + col) * kSmallLd + 16 * j + m];
-            }
-        }
-        pack[e] = v;
-    }
-}
+// Emitted by k_potrf_pack_small above.
 
 // -------------------------------------------------------------- TRSM rows -------
 struct TrsmArgs {
@@ -410,7 +480,8 @@ extern "C" int vt_potrf(double* A, int lda, int D, int* info, void* ws, size_t w
     (void)ws_bytes;
     if (!A || !info || D < 1 || lda < D) return VT_ERR_BAD_ARG;
     if (D > VT_SMALL_D_MAX) return VT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_potrf_small, dim3(1), dim3(512), 0, (hipStream_t)stream, A, lda, D, info);
+    hipLaunchKernelGGL(k_potrf_pack_small, dim3(1), dim3(256), 0, (hipStream_t)stream, A, lda, D, info,
+                       (double*)nullptr, 1);
     return vt_launch_status();
 }
 
@@ -438,7 +509,16 @@ extern "C" size_t vt_trsm_pack_bytes(int D) {
 extern "C" int vt_trsm_pack(const double* L, int ldl, int D, void* pack, void* stream) {
     if (!L || !pack || D < 1 || ldl < D) return VT_ERR_BAD_ARG;
     if (D > VT_SMALL_D_MAX) return VT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_trsm_pack, dim3(1), dim3(256), 0, (hipStream_t)stream, L, ldl, D, (double*)pack);
+    hipLaunchKernelGGL(k_potrf_pack_small, dim3(1), dim3(256), 0, (hipStream_t)stream, (double*)L, ldl, D,
+                       (int*)nullptr, (double*)pack, 0);
+    return vt_launch_status();
+}
+
+extern "C" int vt_potrf_pack(double* A, int lda, int D, int* info, void* pack, void* stream) {
+    if (!A || !info || !pack || D < 1 || lda < D) return VT_ERR_BAD_ARG;
+    if (D > VT_SMALL_D_MAX) return VT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_potrf_pack_small, dim3(1), dim3(256), 0, (hipStream_t)stream, A, lda, D, info,
+                       (double*)pack, 1);
     return vt_launch_status();
 }
 

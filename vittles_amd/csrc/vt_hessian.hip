@@ -108,7 +108,7 @@ __device__ __forceinline__ void hess_small_body(const HessArgs& a, double* gl) {
         double p = 0.0;
 #pragma unroll
         for (int b = 0; b < NB; ++b) p = fma(x[b], th[16 * b + c], p);
-        double z = vt_sum16(p);
+        double z = vt_sum16_dpp(p);
         double yv = sd.y, wv = sd.w;
         if (HAS_OFF) z += sd.off;
         double l1, l2;
@@ -149,45 +149,42 @@ __device__ __forceinline__ void hess_small_body(const HessArgs& a, double* gl) {
         }
     };
 
-    // Pin the interleave: after every MFMA a handful of the link's VALU / LDS ops.
+    // 4-deep register ring, two k-steps per scheduling region: the MFMAs of steps (k, k+1)
+    // are followed by the links of steps (k+2, k+3) -- two independent dependent chains
+    // that the scheduler interleaves -- and the two freed buffers are refilled at once.
+    // While this wave walks its link chains the partner wave on the SIMD owns the matrix pipe.
+    // One wave can issue an fp64 MFMA only every ~140 cycles (measured, tools/micro), the
+    // instruction occupies the pipe for 64: the link's VALU work is placed BETWEEN this wave's
+    // MFMAs in program order, where it is free.
     auto interleave = [&]() {
 #pragma unroll
-        for (int i = 0; i < NH; ++i) {
+        for (int i = 0; i < 2 * NH; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // 6 VALU
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS read (bpermute pair / theta)
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);   // 7 VALU
         }
     };
-
-    // 4-deep register ring over this wave pair's interleaved k-steps: in phase k the
-    // link runs on buffer k+1 (loaded 3 phases ago), the MFMAs on buffer k, and buffer
-    // k is then refilled with step k+4.
     StepData<NB> x0, x1, x2, x3;
     int64_t s = gw;
     load_step<NB, HAS_OFF>(a, s, q, c, x0);
     load_step<NB, HAS_OFF>(a, s + W, q, c, x1);
     load_step<NB, HAS_OFF>(a, s + 2 * W, q, c, x2);
     load_step<NB, HAS_OFF>(a, s + 3 * W, q, c, x3);
-    Link l0 = link(s, x0), l1, l2, l3;
+    Link l0 = link(s, x0), l1 = link(s + W, x1), l2, l3;
     for (; s < nsteps; s += 4 * W) {
         mfmas(x0, l0);
-        l1 = link(s + W, x1);
-        interleave();
-        load_step<NB, HAS_OFF>(a, s + 4 * W, q, c, x0);
-        __builtin_amdgcn_sched_barrier(0);
         mfmas(x1, l1);
         l2 = link(s + 2 * W, x2);
+        l3 = link(s + 3 * W, x3);
         interleave();
+        load_step<NB, HAS_OFF>(a, s + 4 * W, q, c, x0);
         load_step<NB, HAS_OFF>(a, s + 5 * W, q, c, x1);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(x2, l2);
-        l3 = link(s + 3 * W, x3);
-        interleave();
-        load_step<NB, HAS_OFF>(a, s + 6 * W, q, c, x2);
-        __builtin_amdgcn_sched_barrier(0);
         mfmas(x3, l3);
         l0 = link(s + 4 * W, x0);
+        l1 = link(s + 5 * W, x1);
         interleave();
+        load_step<NB, HAS_OFF>(a, s + 6 * W, q, c, x2);
         load_step<NB, HAS_OFF>(a, s + 7 * W, q, c, x3);
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -27,7 +27,7 @@ class DeviceCholesky:
 
     # -- construction -----------------------------------------------------
     @classmethod
-    def factor(cls, H, check=True):
+    def factor(cls, H, check=True, pack=False):
         """Factor a (D, D) CUDA tensor (not modified).  Raises LinAlgError like SciPy
         when H is not positive definite; with ``check=False`` the test is deferred to
         ``raise_if_failed()`` so that dependent kernels can be queued without a sync."""
@@ -36,9 +36,16 @@ class DeviceCholesky:
         if H.ndim != 2 or H.shape[1] != D:
             raise ValueError('Input array needs to be a square matrix.')
         L = H.detach().clone().contiguous()
-        info = torch.zeros(1, dtype=torch.int32, device=L.device)
-        _lib.check(lib.vt_potrf(L.data_ptr(), D, D, info.data_ptr(), 0, 0, dev.stream_ptr()), "vt_potrf")
-        chol = cls(L, info=info)
+        info = torch.empty(1, dtype=torch.int32, device=L.device)
+        pk = None
+        if pack and D <= _lib.SMALL_D_MAX:
+            # one launch: blocked Cholesky + the MFMA TRSM operand images
+            pk = torch.empty(lib.vt_trsm_pack_bytes(D) // 8, dtype=torch.float64, device=L.device)
+            _lib.check(lib.vt_potrf_pack(L.data_ptr(), D, D, info.data_ptr(), pk.data_ptr(), dev.stream_ptr()),
+                       "vt_potrf_pack")
+        else:
+            _lib.check(lib.vt_potrf(L.data_ptr(), D, D, info.data_ptr(), 0, 0, dev.stream_ptr()), "vt_potrf")
+        chol = cls(L, pack=pk, info=info)
         if check:
             chol.raise_if_failed()
         return chol
