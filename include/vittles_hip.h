@@ -163,6 +163,19 @@ int    vt_glm_value(int family, const double* X_dev, int64_t ldx, const double* 
                     const double* y_dev, const double* w_dev, const double* offset_dev, double scale,
                     int64_t N, int D, double* value_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* ---- K6 driver: the BLAS-1 part of one CG iteration, fused into one launch -------------
+ * Replaces: the loop body of scipy.sparse.linalg.cg as called by
+ *             vittles/solver_lib.py:91-97 (SciPy _isolve/iterative.py: rho = r.r;
+ *             p = r + beta p; q = A p; alpha = rho / p.q; x += alpha p; r -= alpha q).
+ * scal_dev: 8 doubles on the device: [0] rho = r.r, [1] ||r||, [2] alpha, [3] p.q, [4] ||b||.
+ * vt_cg_init : r = b - q0 (q0 = A x0; NULL means x0 = 0), p = r, fills scal.
+ * vt_cg_update: given q = A p:  alpha = rho/p.q; x += alpha p; r -= alpha q;
+ *               rho' = r.r; p = r + (rho'/rho) p.  The host reads scal[1] to test convergence. */
+int    vt_cg_init(const double* b_dev, const double* q0_dev, double* r_dev, double* p_dev, int64_t D,
+                  double* scal_dev, void* stream);
+int    vt_cg_update(double* p_dev, const double* q_dev, double* x_dev, double* r_dev, int64_t D,
+                    double* scal_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,94 @@
+// K6 driver pieces: the BLAS-1 part of one conjugate-gradient iteration, fused in ONE launch.
+// Replaces the five NumPy vector operations per iteration inside scipy.sparse.linalg.cg as the
+// reference calls it (vittles/solver_lib.py:91-97; SciPy's loop: rho = r.r; p = r + beta p;
+// q = A p; alpha = rho / p.q; x += alpha p; r -= alpha q).  The matrix-vector product q = A p is
+// the fused HVP kernel (vt_glm_hvp) or a user callable; everything else is this kernel.
+//
+// All vectors are replicated on every rank (D doubles: 160 KB at D = 20k), so no collective is
+// needed here; a single 1024-thread workgroup walks them (deterministic reductions).
+#include "vt_common.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = vt_sum64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i];
+    return s;
+}
+
+// scal[0] = rho (in: r.r of the current residual; out: of the new one), scal[1] = ||r_new||,
+// scal[2] = alpha, scal[3] = p.q.
+//   alpha = rho / p.q;  x += alpha p;  r -= alpha q;  rho' = r.r;  p = r + (rho'/rho) p
+__global__ __launch_bounds__(1024) void k_cg_update(double* p, const double* q, double* x, double* r, int64_t D,
+                                                    double* scal) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    double pq = 0.0;
+    for (int64_t i = tid; i < D; i += 1024) pq = fma(p[i], q[i], pq);
+    pq = block_sum(pq, red);
+    const double rho = scal[0];
+    const double alpha = rho / pq;
+    double rr = 0.0;
+    for (int64_t i = tid; i < D; i += 1024) {
+        x[i] = fma(alpha, p[i], x[i]);
+        double ri = fma(-alpha, q[i], r[i]);
+        r[i] = ri;
+        rr = fma(ri, ri, rr);
+    }
+    rr = block_sum(rr, red);
+    const double beta = rr / rho;
+    for (int64_t i = tid; i < D; i += 1024) p[i] = fma(beta, p[i], r[i]);
+    if (tid == 0) {
+        scal[0] = rr;
+        scal[1] = sqrt(rr);
+        scal[2] = alpha;
+        scal[3] = pq;
+    }
+}
+
+// Start of a solve: r = b - q0 (q0 = A x0, or NULL for x0 = 0), p = r, scal[0] = r.r, scal[1] = ||r||,
+// scal[4] = ||b||.
+__global__ __launch_bounds__(1024) void k_cg_init(const double* b, const double* q0, double* r, double* p,
+                                                  int64_t D, double* scal) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    double rr = 0.0, bb = 0.0;
+    for (int64_t i = tid; i < D; i += 1024) {
+        double bi = b[i];
+        double ri = q0 ? bi - q0[i] : bi;
+        r[i] = ri;
+        p[i] = ri;
+        rr = fma(ri, ri, rr);
+        bb = fma(bi, bi, bb);
+    }
+    rr = block_sum(rr, red);
+    bb = block_sum(bb, red);
+    if (tid == 0) {
+        scal[0] = rr;
+        scal[1] = sqrt(rr);
+        scal[2] = 0.0;
+        scal[3] = 0.0;
+        scal[4] = sqrt(bb);
+    }
+}
+
+}  // namespace
+
+extern "C" int vt_cg_init(const double* b, const double* q0, double* r, double* p, int64_t D, double* scal,
+                          void* stream) {
+    if (!b || !r || !p || !scal || D < 1) return VT_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(1024), 0, (hipStream_t)stream, b, q0, r, p, D, scal);
+    return vt_launch_status();
+}
+
+extern "C" int vt_cg_update(double* p, const double* q, double* x, double* r, int64_t D, double* scal,
+                            void* stream) {
+    if (!p || !q || !x || !r || !scal || D < 1) return VT_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_cg_update, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, q, x, r, D, scal);
+    return vt_launch_status();
+}
