@@ -176,6 +176,58 @@ int    vt_cg_init(const double* b_dev, const double* q0_dev, double* r_dev, doub
 int    vt_cg_update(double* p_dev, const double* q_dev, double* x_dev, double* r_dev, int64_t D,
                     double* scal_dev, void* stream);
 
+/* ---- K7: hierarchical mean-field Gaussian VI objective (BASELINE.json configs[4]) --------
+ * Model and parameter layout: see oracle/vi.py / vittles_amd/objectives.py.
+ * eta = [m_0 v_0 ... m_{G-1} v_{G-1} m_mu v_mu], d = 2k(G+1); X is (G*ng, k) row-major.
+ * Replaces: autograd.grad(f) and the forward-over-reverse HVP `_f_fwd_hess`
+ *             vittles/sparse_hessian_lib.py:59-60 (vittles/sensitivity_lib.py:440-492),
+ *             vittles/lr_cov_lib.py:77-80, for this registered objective. */
+size_t vt_vi_workspace_bytes(int G, int k);
+int    vt_vi_hvp(const double* X_dev, const double* w_dev, const double* eta_dev, const double* u_dev,
+                 double tau_y, double tau_th, double tau_mu, int G, int ng, int k, double* out_dev,
+                 void* ws_dev, size_t ws_bytes, void* stream);
+int    vt_vi_grad(const double* X_dev, const double* y_dev, const double* w_dev, const double* eta_dev,
+                  double tau_y, double tau_th, double tau_mu, int G, int ng, int k, double* out_dev,
+                  void* ws_dev, size_t ws_bytes, void* stream);
+int    vt_vi_value(const double* X_dev, const double* y_dev, const double* w_dev, const double* eta_dev,
+                   double tau_y, double tau_th, double tau_mu, int G, int ng, int k, double* value_dev,
+                   void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ---- K7: SparseBlockHessian assembly ------------------------------------------------------
+ * vt_block_colour_vec: v <- 0; v[inds[b, ib]] = 1 for all b
+ *   Replaces: SparseBlockHessian._hess_summed_term   vittles/sparse_hessian_lib.py:62-67
+ * vt_block_gather: after HVP number ib, COO triplets e = (ib*G + b)*M + r in the reference's
+ *   order plus the dense image blocks[b][r][ib].
+ *   Replaces: the Python double loop            vittles/sparse_hessian_lib.py:93-102
+ * vt_global_gather: after the HVP of global index number jg: 2*nloc + 2*Kg triplets in the
+ *   reference's order (two 0.5*h halves for global pairs) plus border[(b*M+r)][jg], corner[j2][jg].
+ *   Replaces: get_global_hessian's loops         vittles/sparse_hessian_lib.py:130-156 */
+int    vt_block_colour_vec(const int64_t* inds_dev, int G, int M, int ib, double* v_dev, int64_t d,
+                           void* stream);
+int    vt_block_gather(const double* hv_dev, const int64_t* inds_dev, int G, int M, int ib,
+                       double* vals_dev, int64_t* rows_dev, int64_t* cols_dev, double* blocks_dev,
+                       void* stream);
+int    vt_global_gather(const double* hrow_dev, const int64_t* local_inds_dev, int64_t nloc,
+                        const int64_t* ginds_dev, int Kg, int jg, double* vals_dev, int64_t* rows_dev,
+                        int64_t* cols_dev, double* border_dev, double* corner_dev, void* stream);
+
+/* ---- K8: batched block-arrowhead solver  H = [[blockdiag(B_g), C], [C^T, Gm]] ---------------
+ * Replaces: scipy.sparse.linalg.factorized(h) (SuperLU)   vittles/solver_lib.py:46-48
+ *           as used by vittles/lr_cov_lib.py:106, 111, 172.
+ * vt_arrow_factor: B_g <- chol(B_g) in place, W_g = B_g^{-1} C_g, schur = Gm - sum_g C_g^T W_g
+ *   (*info_dev: 0 or 1 + flat index of the first non-positive pivot).
+ * vt_arrow_local_solve: x[inds] <- B^{-1} v[inds];  rhs_glob <- -sum_g C_g^T x_g  (Kg x nrhs);
+ *   v, x are (d, nrhs) row-major.
+ * vt_arrow_back: x[inds] -= W x_glob;  x[ginds] <- x_glob. */
+int    vt_arrow_factor(double* blocks_dev, const double* border_dev, const double* corner_dev,
+                       double* W_dev, double* spart_dev, double* schur_dev, int G, int M, int Kg,
+                       int* info_dev, void* stream);
+int    vt_arrow_local_solve(const double* blocks_dev, const double* border_dev, const int64_t* inds_dev,
+                            const int64_t* ginds_dev, const double* v_dev, double* x_dev, double* tpart_dev,
+                            double* rhs_glob_dev, int G, int M, int Kg, int nrhs, void* stream);
+int    vt_arrow_back(const double* W_dev, const int64_t* inds_dev, const int64_t* ginds_dev,
+                     const double* xg_dev, double* x_dev, int G, int M, int Kg, int nrhs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

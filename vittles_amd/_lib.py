@@ -48,6 +48,21 @@ SIGNATURES = {
     "vt_gemv": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size_t, c_ptr]),
     "vt_cg_init": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "vt_cg_update": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    "vt_vi_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "vt_vi_hvp": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_dbl, c_dbl, c_int, c_int, c_int, c_ptr,
+                          c_ptr, c_size_t, c_ptr]),
+    "vt_vi_grad": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_dbl, c_dbl, c_int, c_int, c_int, c_ptr,
+                           c_ptr, c_size_t, c_ptr]),
+    "vt_vi_value": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_dbl, c_dbl, c_int, c_int, c_int, c_ptr,
+                            c_ptr, c_size_t, c_ptr]),
+    "vt_block_colour_vec": (c_int, [c_ptr, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
+    "vt_block_gather": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "vt_global_gather": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
+                                 c_ptr, c_ptr]),
+    "vt_arrow_factor": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "vt_arrow_local_solve": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int,
+                                     c_int, c_int, c_ptr]),
+    "vt_arrow_back": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "vt_glm_value": (c_int, [c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_i64, c_int,
                              c_ptr, c_ptr, c_size_t, c_ptr]),
 }

@@ -10,7 +10,7 @@ methods of the objective, computed in closed form on the device.
 import numpy as np
 import torch
 
-from . import _lib, device as dev
+from . import _lib, device as dev, sharding
 
 
 class RegisteredObjective:
@@ -87,16 +87,10 @@ class WeightedGLMObjective(RegisteredObjective):
 
     # ---- distributed plumbing ------------------------------------------------
     def _rank(self):
-        if self.process_group is None:
-            return 0
-        import torch.distributed as dist
-        return dist.get_rank(self.process_group)
+        return sharding.group_rank(self.process_group)
 
     def _all_reduce(self, t):
-        if self.process_group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
-        return t
+        return sharding.all_reduce_sum(t, self.process_group)
 
     # ---- fused pass ------------------------------------------------------------
     def fused(self, theta, w):
@@ -127,8 +121,7 @@ class WeightedGLMObjective(RegisteredObjective):
             self.y.data_ptr(), w.data_ptr(), dev.ptr(self.offset), self.scale, dev.ptr(prior),
             self.N, self.D, H.data_ptr(), self.D, g.data_ptr(), r.data_ptr(), d.data_ptr(),
             self._ws.data_ptr(), self._ws.numel() * 8, dev.stream_ptr()), "vt_glm_hessian")
-        self._all_reduce(H)
-        self._all_reduce(g)
+        self._all_reduce([H, g])      # one RCCL message: D*D + D doubles
         out = dict(H=H, g=g, r=r, d=d, theta=theta, w=w)
         self._cache_key, self._cache = key, out
         return out
@@ -145,3 +138,90 @@ class WeightedGLMObjective(RegisteredObjective):
     def value(self, opt, hyper):
         from . import rows
         return rows.glm_value(self, opt, hyper)
+
+
+class HierGaussMFVIObjective(RegisteredObjective):
+    r"""Hierarchical mean-field Gaussian VI objective (KL(q || posterior) up to a constant):
+
+        y_gi ~ N(x_gi . theta_g, 1/tau_y),  theta_g ~ N(mu, I/tau_th),  mu ~ N(0, I/tau_mu)
+        q(theta_g) = N(m_g, diag v_g),  q(mu) = N(m_mu, diag v_mu)
+
+    ``opt_par`` layout: [m_0, v_0, ..., m_{G-1}, v_{G-1}, m_mu, v_mu] (each piece k long),
+    d = 2k(G+1); the Hessian is block diagonal (G blocks of 2k) plus a 2k-wide arrowhead
+    border for the globals.  ``hyper_par`` = per-row data weights (G*ng,), default 1.
+    It is a callable ``f(opt_par[, weights])`` like the reference expects, and carries its
+    gradient and HVP as HIP kernels (the reference would use autograd)."""
+
+    def __init__(self, X, y, G, ng, k, tau_y=1.0, tau_th=1.0, tau_mu=1.0, device=None):
+        dev.require_gpu()
+        self.G, self.ng, self.k = int(G), int(ng), int(k)
+        self.X = dev.to_device(X, device).reshape(self.G * self.ng, self.k).contiguous()
+        self.device = self.X.device
+        self.y = dev.to_device(y, self.device).reshape(-1).contiguous()
+        if self.y.shape[0] != self.G * self.ng:
+            raise ValueError("y must have G*ng entries")
+        self.tau = (float(tau_y), float(tau_th), float(tau_mu))
+        self.d = 2 * self.k * (self.G + 1)
+        self._ones = torch.ones(self.G * self.ng, dtype=torch.float64, device=self.device)
+        lib = _lib.load()
+        self._ws = torch.empty(lib.vt_vi_workspace_bytes(self.G, self.k) // 8 + 1, dtype=torch.float64,
+                               device=self.device)
+
+    def sparsity_array(self):
+        return np.arange(2 * self.k * self.G).reshape(self.G, 2 * self.k)
+
+    def global_inds(self):
+        return np.arange(2 * self.k * self.G, self.d)
+
+    def _w(self, hyper):
+        return self._ones if hyper is None else dev.to_device(hyper, self.device).contiguous()
+
+    def _check(self, opt):
+        opt = dev.to_device(opt, self.device).contiguous()
+        if opt.shape != (self.d,):
+            raise ValueError("opt_par must have shape (%d,)" % self.d)
+        return opt
+
+    def __call__(self, opt_par, hyper_par=None):
+        return self.value(opt_par, hyper_par)
+
+    def value(self, opt, hyper=None):
+        lib = dev.require_gpu()
+        opt = self._check(opt)
+        val = torch.empty(1, dtype=torch.float64, device=self.device)
+        _lib.check(lib.vt_vi_value(self.X.data_ptr(), self.y.data_ptr(), self._w(hyper).data_ptr(), opt.data_ptr(),
+                                   *self.tau, self.G, self.ng, self.k, val.data_ptr(), self._ws.data_ptr(),
+                                   self._ws.numel() * 8, dev.stream_ptr()), "vt_vi_value")
+        return float(val.item())
+
+    def grad(self, opt, hyper=None):
+        lib = dev.require_gpu()
+        opt = self._check(opt)
+        out = torch.empty(self.d, dtype=torch.float64, device=self.device)
+        _lib.check(lib.vt_vi_grad(self.X.data_ptr(), self.y.data_ptr(), self._w(hyper).data_ptr(), opt.data_ptr(),
+                                  *self.tau, self.G, self.ng, self.k, out.data_ptr(), self._ws.data_ptr(),
+                                  self._ws.numel() * 8, dev.stream_ptr()), "vt_vi_grad")
+        return out
+
+    def hvp(self, opt, vec, hyper=None, out=None):
+        lib = dev.require_gpu()
+        opt = self._check(opt)
+        vec = dev.to_device(vec, self.device).contiguous()
+        if out is None:
+            out = torch.empty(self.d, dtype=torch.float64, device=self.device)
+        _lib.check(lib.vt_vi_hvp(self.X.data_ptr(), self._w(hyper).data_ptr(), opt.data_ptr(), vec.data_ptr(),
+                                 *self.tau, self.G, self.ng, self.k, out.data_ptr(), self._ws.data_ptr(),
+                                 self._ws.numel() * 8, dev.stream_ptr()), "vt_vi_hvp")
+        return out
+
+    def hessian(self, opt, hyper=None):
+        """Dense (d, d) Hessian by d HVPs -- small problems only (tests, validation)."""
+        if self.d > 4096:
+            raise _lib.VittlesHipError("dense Hessian of a d=%d VI objective: use SparseBlockHessian" % self.d)
+        H = torch.empty((self.d, self.d), dtype=torch.float64, device=self.device)
+        e = torch.zeros(self.d, dtype=torch.float64, device=self.device)
+        for j in range(self.d):
+            e[j] = 1.0
+            self.hvp(opt, e, hyper, out=H[j])
+            e[j] = 0.0
+        return H   # symmetric: rows == columns
