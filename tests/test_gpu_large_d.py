@@ -1,0 +1,62 @@
+"""GPU parity of the large-D (D > 128) dense path: tiled SYRK, blocked Cholesky, blocked MFMA TRSM
+(BASELINE.json configs[2] shape class, D = 1000) against the oracle."""
+import numpy as np
+import pytest
+import scipy.linalg
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.mark.parametrize("D", [129, 200, 256, 333, 1000])
+def test_potrf_potrs_large(D, relerr):
+    import torch
+    from vittles_amd.linalg import DeviceCholesky
+    rng = np.random.default_rng(D)
+    A = rng.standard_normal((2 * D, D))
+    H = A.T @ A / D + np.eye(D)
+    chol = DeviceCholesky.factor(torch.tensor(H, device="cuda"), pack=(D % 2 == 0))
+    L = np.tril(chol.L.cpu().numpy())
+    assert relerr(L, np.linalg.cholesky(H)) < TOL
+    B = rng.standard_normal((D, 300))
+    ref = scipy.linalg.cho_solve(scipy.linalg.cho_factor(H), B)
+    got = chol.solve(torch.tensor(B, device="cuda"))
+    assert got.shape == (D, 300) and relerr(got.cpu().numpy(), ref) < 1e-9
+    v = rng.standard_normal(D)
+    assert relerr(chol.solve(torch.tensor(v, device="cuda")).cpu().numpy(), np.linalg.solve(H, v)) < 1e-9
+    # identity: exact pass-through of an asymmetric right-hand side
+    I = DeviceCholesky.factor(torch.eye(D, dtype=torch.float64, device="cuda"))
+    Bm = torch.arange(70 * D, dtype=torch.float64, device="cuda").reshape(70, D) + 1.0
+    assert torch.equal(I.solve_rows(Bm), Bm)
+
+
+def test_potrf_large_not_positive_definite():
+    import torch
+    from vittles_amd.linalg import DeviceCholesky
+    H = np.eye(300)
+    H[200, 200] = -1.0
+    with pytest.raises(np.linalg.LinAlgError) as e:
+        DeviceCholesky.factor(torch.tensor(H, device="cuda"))
+    assert "201-th leading minor" in str(e.value)
+
+
+@pytest.mark.parametrize("N,D,family", [(3000, 130, "logistic"), (5000, 257, "gaussian"), (20000, 1000, "logistic"),
+                                         (1501, 1001, "poisson")])
+def test_sensitivity_large_d(N, D, family, relerr):
+    from oracle import glm
+    import vittles_amd as va
+    X, y, w, _ = glm.synth(N, D, family, seed=N + D)
+    rng = np.random.default_rng(1)
+    w = 0.5 + rng.random(N)
+    prior = 1.0
+    theta = glm.newton_optimum(family, X, y, w, prior=prior)
+    obj = va.WeightedGLMObjective(X, y, family=family, prior=prior)
+    out = obj.fused(theta, w)
+    H_ref, jac0, S_ref = glm.sensitivity(family, X, y, theta, w, prior=prior)
+    H = out["H"].cpu().numpy()
+    assert relerr(H, H_ref) < TOL and np.array_equal(H, H.T)
+    assert relerr(out["g"].cpu().numpy() + 1.0, glm.grad(family, X, y, theta, w, prior=prior) + 1.0) < TOL
+    sens = va.HyperparameterSensitivityLinearApproximation(obj, theta, w, validate_optimum=True, grad_tol=1e-7)
+    assert relerr(sens.get_dopt_dhyper(), S_ref) < TOL
+    w1 = w * (1.0 + 0.01 * np.cos(np.arange(N)))
+    assert relerr(sens.predict_opt_par_from_hyper_par(w1), theta + S_ref @ (w1 - w)) < TOL

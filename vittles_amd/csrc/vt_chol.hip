@@ -242,6 +242,7 @@ struct TrsmArgs {
     int D;
     double* Out;
     int64_t ldo;
+    int mode;   // 0: full solve (L L^T)^{-1};  1: forward only  L^{-1};  2: backward only  L^{-T}
 };
 
 // Out[n,:] = alpha * s_n * (L L^T)^{-1} B[n,:].   D <= 128.
@@ -299,16 +300,32 @@ struct TrsmState {
     double cur[4], nxt[4];
     const double* lds;
     int lane, q;
-    double* orow;  // output row of this lane (nullptr-safe through `store`)
-    bool store;
+    double* orow;  // output row of this lane
+    bool store_fwd, store_bwd;   // store Y after the forward chain (forward-only solves) / Z after the backward chain
     int D;
 };
 
-template <int IDX, int NB, int KL, bool LASTPERM>
-__device__ __forceinline__ void trsm_product(TrsmState<NB, KL, LASTPERM>& st) {
+template <int J, int NB, int KL, bool LASTPERM>
+__device__ __forceinline__ void trsm_store(TrsmState<NB, KL, LASTPERM>& st) {
     using S = TrsmSched<NB, KL, LASTPERM>;
-    if constexpr (IDX < S::M) {
-        if constexpr (IDX + 1 < S::M) {
+    if constexpr (S::permuted(J)) {
+        *(f64x2u*)(st.orow + 16 * J + 4 * st.q) = (f64x2u){st.acc[0], st.acc[1]};
+        *(f64x2u*)(st.orow + 16 * J + 4 * st.q + 2) = (f64x2u){st.acc[2], st.acc[3]};
+    } else {
+#pragma unroll
+        for (int s = 0; s < KL; ++s) {
+            int col = 16 * J + 4 * s + st.q;
+            if (col < st.D) st.orow[col] = st.acc[s];
+        }
+    }
+}
+
+// Products [IDX, END) of the schedule; st.cur holds the A operand of product IDX on entry.
+template <int IDX, int END, int NB, int KL, bool LASTPERM>
+__device__ __forceinline__ void trsm_chain(TrsmState<NB, KL, LASTPERM>& st) {
+    using S = TrsmSched<NB, KL, LASTPERM>;
+    if constexpr (IDX < END) {
+        if constexpr (IDX + 1 < END) {
             constexpr int img = S::image(IDX + 1);
             constexpr int nks = S::ks(S::src(IDX + 1));
 #pragma unroll
@@ -323,25 +340,12 @@ __device__ __forceinline__ void trsm_product(TrsmState<NB, KL, LASTPERM>& st) {
         for (int s = 0; s < cks; ++s) st.acc = mfma_f64(st.cur[s], st.V[i][s], st.acc);
         if constexpr (is_last) {
             st.V[j] = st.acc;
-            if constexpr (is_bwd) {
-                if (st.store) {
-                    if constexpr (S::permuted(j)) {
-                        *(f64x2u*)(st.orow + 16 * j + 4 * st.q) = (f64x2u){st.acc[0], st.acc[1]};
-                        *(f64x2u*)(st.orow + 16 * j + 4 * st.q + 2) = (f64x2u){st.acc[2], st.acc[3]};
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < KL; ++s) {
-                            int col = 16 * j + 4 * s + st.q;
-                            if (col < st.D) st.orow[col] = st.acc[s];
-                        }
-                    }
-                }
-            }
+            if (is_bwd ? st.store_bwd : st.store_fwd) trsm_store<j, NB, KL, LASTPERM>(st);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) st.cur[s] = st.nxt[s];
-        trsm_product<IDX + 1, NB, KL, LASTPERM>(st);
+        trsm_chain<IDX + 1, END, NB, KL, LASTPERM>(st);
     }
 }
 
@@ -413,16 +417,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) st.V[b] = Gn[b] * coefn;
         int64_t row = grp * 16 + n;
-        st.store = row < a.N;
-        st.orow = a.Out + (st.store ? row : 0) * a.ldo;
+        const bool rowok = row < a.N;
+        st.store_fwd = rowok && a.mode == 1;
+        st.store_bwd = rowok && a.mode != 1;
+        st.orow = a.Out + (rowok ? row : 0) * a.ldo;
         load_group(grp + W < ngroups ? grp + W : grp);
-        {
+        if (a.mode != 2) {   // forward substitution  L Y = G
             constexpr int img = S::image(0);
             constexpr int nks = S::ks(S::src(0));
 #pragma unroll
             for (int s = 0; s < nks; ++s) st.cur[s] = lds[(img * 4 + s) * 64 + lane];
+            trsm_chain<0, NBT, NB, KL, LASTPERM>(st);
         }
-        trsm_product<0, NB, KL, LASTPERM>(st);
+        if (a.mode != 1) {   // backward substitution  L^T Z = Y
+            constexpr int img = S::image(NBT);
+            constexpr int nks = S::ks(S::src(NBT));
+#pragma unroll
+            for (int s = 0; s < nks; ++s) st.cur[s] = lds[(img * 4 + s) * 64 + lane];
+            trsm_chain<NBT, 2 * NBT, NB, KL, LASTPERM>(st);
+        }
     }
 }
 
@@ -470,19 +483,43 @@ int dispatch_trsm_kl(const TrsmArgs& a, hipStream_t st) {
 
 }  // namespace
 
+int vt_potrf_pack_block(double* A, int lda, int D, int* info, double* pack, int do_factor, hipStream_t st) {
+    hipLaunchKernelGGL(k_potrf_pack_small, dim3(1), dim3(256), 0, st, A, lda, D, info, pack, do_factor);
+    return vt_launch_status();
+}
+
+int vt_trsm_rows_mode(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
+                      int64_t N, double* Out, int64_t ldo, int mode, hipStream_t st) {
+    if (N == 0) return VT_OK;
+    TrsmArgs a{(const double*)pack, B, ldb, rowscale, alpha, N, D, Out, ldo, mode};
+    switch ((D + 15) / 16) {
+        case 1: dispatch_trsm_kl<1>(a, st); break;
+        case 2: dispatch_trsm_kl<2>(a, st); break;
+        case 3: dispatch_trsm_kl<3>(a, st); break;
+        case 4: dispatch_trsm_kl<4>(a, st); break;
+        case 5: dispatch_trsm_kl<5>(a, st); break;
+        case 6: dispatch_trsm_kl<6>(a, st); break;
+        case 7: dispatch_trsm_kl<7>(a, st); break;
+        case 8: dispatch_trsm_kl<8>(a, st); break;
+        default: return VT_ERR_UNSUPPORTED;
+    }
+    return vt_launch_status();
+}
+
+constexpr int kLargeDMax = 8192;   // D x D images of L and L^T live in the pack
+
 extern "C" size_t vt_potrf_workspace_bytes(int D) {
-    (void)D;
-    return 0;
+    return D > VT_SMALL_D_MAX ? vt_large_potrf_ws_bytes(D) : 0;
 }
 
 extern "C" int vt_potrf(double* A, int lda, int D, int* info, void* ws, size_t ws_bytes, void* stream) {
-    (void)ws;
-    (void)ws_bytes;
     if (!A || !info || D < 1 || lda < D) return VT_ERR_BAD_ARG;
-    if (D > VT_SMALL_D_MAX) return VT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_potrf_pack_small, dim3(1), dim3(256), 0, (hipStream_t)stream, A, lda, D, info,
-                       (double*)nullptr, 1);
-    return vt_launch_status();
+    if (D > kLargeDMax) return VT_ERR_UNSUPPORTED;
+    if (D > VT_SMALL_D_MAX) {
+        if (!ws || ws_bytes < vt_large_potrf_ws_bytes(D)) return VT_ERR_WORKSPACE;
+        return vt_large_potrf(A, lda, D, info, ws, (hipStream_t)stream);
+    }
+    return vt_potrf_pack_block(A, lda, D, info, nullptr, 1, (hipStream_t)stream);
 }
 
 extern "C" int vt_potrs(const double* L, int ldl, int D, double* B, int64_t ldb_row, int64_t ldb_col,
@@ -501,44 +538,38 @@ extern "C" int vt_potrs(const double* L, int ldl, int D, double* B, int64_t ldb_
 }
 
 extern "C" size_t vt_trsm_pack_bytes(int D) {
-    if (D < 1 || D > VT_SMALL_D_MAX) return 0;
+    if (D < 1 || D > kLargeDMax) return 0;
+    if (D > VT_SMALL_D_MAX) return vt_large_pack_bytes(D);
     int NB = (D + 15) / 16;
     return (size_t)2 * (NB * (NB + 1) / 2) * 256 * sizeof(double);
 }
 
 extern "C" int vt_trsm_pack(const double* L, int ldl, int D, void* pack, void* stream) {
     if (!L || !pack || D < 1 || ldl < D) return VT_ERR_BAD_ARG;
-    if (D > VT_SMALL_D_MAX) return VT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_potrf_pack_small, dim3(1), dim3(256), 0, (hipStream_t)stream, (double*)L, ldl, D,
-                       (int*)nullptr, (double*)pack, 0);
-    return vt_launch_status();
+    if (D > kLargeDMax) return VT_ERR_UNSUPPORTED;
+    if (D > VT_SMALL_D_MAX) return vt_large_pack(L, ldl, D, pack, (hipStream_t)stream);
+    return vt_potrf_pack_block((double*)L, ldl, D, nullptr, (double*)pack, 0, (hipStream_t)stream);
 }
 
 extern "C" int vt_potrf_pack(double* A, int lda, int D, int* info, void* pack, void* stream) {
     if (!A || !info || !pack || D < 1 || lda < D) return VT_ERR_BAD_ARG;
-    if (D > VT_SMALL_D_MAX) return VT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_potrf_pack_small, dim3(1), dim3(256), 0, (hipStream_t)stream, A, lda, D, info,
-                       (double*)pack, 1);
-    return vt_launch_status();
+    if (D > kLargeDMax) return VT_ERR_UNSUPPORTED;
+    if (D > VT_SMALL_D_MAX) {
+        // the L / L^T images of the pack (2 D^2 doubles) are free until vt_large_pack fills them:
+        // they serve as the factorisation's scratch.
+        int rc = vt_large_potrf(A, lda, D, info, pack, (hipStream_t)stream);
+        if (rc != VT_OK) return rc;
+        return vt_large_pack(A, lda, D, pack, (hipStream_t)stream);
+    }
+    return vt_potrf_pack_block(A, lda, D, info, (double*)pack, 1, (hipStream_t)stream);
 }
 
 extern "C" int vt_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale,
                             double alpha, int64_t N, double* Out, int64_t ldo, void* stream) {
     if (!pack || !B || !Out || D < 1 || ldb < D || ldo < D || N < 0) return VT_ERR_BAD_ARG;
-    if (D > VT_SMALL_D_MAX) return VT_ERR_UNSUPPORTED;
+    if (D > kLargeDMax) return VT_ERR_UNSUPPORTED;
     if (N == 0) return VT_OK;
-    TrsmArgs a{(const double*)pack, B, ldb, rowscale, alpha, N, D, Out, ldo};
-    hipStream_t st = (hipStream_t)stream;
-    switch ((D + 15) / 16) {
-        case 1: dispatch_trsm_kl<1>(a, st); break;
-        case 2: dispatch_trsm_kl<2>(a, st); break;
-        case 3: dispatch_trsm_kl<3>(a, st); break;
-        case 4: dispatch_trsm_kl<4>(a, st); break;
-        case 5: dispatch_trsm_kl<5>(a, st); break;
-        case 6: dispatch_trsm_kl<6>(a, st); break;
-        case 7: dispatch_trsm_kl<7>(a, st); break;
-        case 8: dispatch_trsm_kl<8>(a, st); break;
-        default: return VT_ERR_UNSUPPORTED;
-    }
-    return vt_launch_status();
+    if (D > VT_SMALL_D_MAX)
+        return vt_large_trsm_rows(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, (hipStream_t)stream);
+    return vt_trsm_rows_mode(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, 0, (hipStream_t)stream);
 }

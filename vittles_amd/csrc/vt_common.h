@@ -108,3 +108,18 @@ __device__ __forceinline__ double vt_sum64(double v) {
 
 // Index of the (a, b) block, a >= b, in packed lower-triangular block order.
 __host__ __device__ __forceinline__ constexpr int vt_tri(int a, int b) { return a * (a + 1) / 2 + b; }
+
+// ---- internal (non-exported) entry points shared between translation units -------------------
+#include <algorithm>
+int vt_potrf_pack_block(double* A, int lda, int D, int* info, double* pack, int do_factor, hipStream_t st);
+int vt_trsm_rows_mode(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
+                      int64_t N, double* Out, int64_t ldo, int mode, hipStream_t st);
+size_t vt_large_potrf_ws_bytes(int D);
+int vt_large_potrf(double* A, int lda, int D, int* info, void* ws, hipStream_t st);
+size_t vt_large_pack_bytes(int D);
+int vt_large_pack(const double* L, int ldl, int D, void* pack, hipStream_t st);
+int vt_large_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
+                       int64_t N, double* Out, int64_t ldo, hipStream_t st);
+size_t vt_large_syrk_ws_bytes(int D);
+int vt_large_syrk(const double* X, int64_t ldx, const double* d, int64_t N, int D, const double* prior, double* H,
+                  int ldh, void* ws, hipStream_t st);

@@ -320,8 +320,19 @@ void launch_hess_small(const HessArgs& a, int grid, hipStream_t st) {
 
 }  // namespace
 
+extern "C" size_t vt_rows_workspace_bytes(int D);
+extern "C" int vt_glm_grad(int family, const double* X, int64_t ldx, const double* theta, const double* y,
+                           const double* w, const double* offset, double scale, const double* prior,
+                           int64_t N, int D, double* g_out, double* r_out, double* d_out, void* ws,
+                           size_t ws_bytes, void* stream);
+
+// D > 128: link + gradient by the row-streaming kernel (one pass), then the tiled SYRK.
+static size_t large_ws_rows(int D) { return (vt_rows_workspace_bytes(D) + 255) / 256 * 256; }
+
 extern "C" size_t vt_glm_hessian_workspace_bytes(int64_t N, int D) {
-    if (D < 1 || D > VT_SMALL_D_MAX) return 0;
+    if (D < 1) return 0;
+    if (D > VT_SMALL_D_MAX)
+        return large_ws_rows(D) + (size_t)(N + D + 64) * sizeof(double) + vt_large_syrk_ws_bytes(D);
     int NB = (D + 15) / 16;
     return ((size_t)(num_cu() + kStage2) * slab_len(NB) + (size_t)num_cu() * 4 * (NB * (NB + 1) / 2) * 256 + 1024) *
            sizeof(double);
@@ -333,9 +344,20 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
                               double* r, double* d, void* ws, size_t ws_bytes, void* stream) {
     if (!X || !theta || !y || !w || !H || N < 0 || D < 1 || ldx < D || ldh < D) return VT_ERR_BAD_ARG;
     if (family < 0 || family > 2) return VT_ERR_BAD_ARG;
-    if (D > VT_SMALL_D_MAX) return VT_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < vt_glm_hessian_workspace_bytes(N, D)) return VT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (D > VT_SMALL_D_MAX) {
+        char* base = (char*)ws;
+        double* dtmp = (double*)(base + large_ws_rows(D));
+        double* gtmp = dtmp + N;
+        size_t off = large_ws_rows(D) + (size_t)(N + D) * sizeof(double);
+        void* syrk_ws = (void*)(base + (off + 255) / 256 * 256);
+        double* dd = d ? d : dtmp;
+        int rc = vt_glm_grad(family, X, ldx, theta, y, w, offset, scale, prior, N, D, g ? g : gtmp, r, dd, ws,
+                             large_ws_rows(D), stream);
+        if (rc != VT_OK) return rc;
+        return vt_large_syrk(X, ldx, dd, N, D, prior, H, ldh, syrk_ws, st);
+    }
     const int NB = (D + 15) / 16;
     const int L = slab_len(NB);
     const int grid = hess_grid(N);

@@ -38,13 +38,16 @@ class DeviceCholesky:
         L = H.detach().clone().contiguous()
         info = torch.empty(1, dtype=torch.int32, device=L.device)
         pk = None
-        if pack and D <= _lib.SMALL_D_MAX:
+        if pack and lib.vt_trsm_pack_bytes(D) > 0:
             # one launch: blocked Cholesky + the MFMA TRSM operand images
             pk = torch.empty(lib.vt_trsm_pack_bytes(D) // 8, dtype=torch.float64, device=L.device)
             _lib.check(lib.vt_potrf_pack(L.data_ptr(), D, D, info.data_ptr(), pk.data_ptr(), dev.stream_ptr()),
                        "vt_potrf_pack")
         else:
-            _lib.check(lib.vt_potrf(L.data_ptr(), D, D, info.data_ptr(), 0, 0, dev.stream_ptr()), "vt_potrf")
+            nws = lib.vt_potrf_workspace_bytes(D)
+            ws = torch.empty(nws // 8 + 1, dtype=torch.float64, device=L.device) if nws else None
+            _lib.check(lib.vt_potrf(L.data_ptr(), D, D, info.data_ptr(), dev.ptr(ws), nws, dev.stream_ptr()),
+                       "vt_potrf")
         chol = cls(L, pack=pk, info=info)
         if check:
             chol.raise_if_failed()
@@ -72,7 +75,7 @@ class DeviceCholesky:
                                     dev.stream_ptr()), "vt_potrs")
             return x
         K = v.shape[1]
-        if self.D <= _lib.SMALL_D_MAX and K >= 64:
+        if K >= 64 and lib.vt_trsm_pack_bytes(self.D) > 0:
             # MFMA TRSM wants right-hand sides as rows: (K, D) row-major.
             rows = v.detach().t().contiguous()
             out = self.solve_rows(rows)
@@ -87,7 +90,7 @@ class DeviceCholesky:
             lib = dev.require_gpu()
             nbytes = lib.vt_trsm_pack_bytes(self.D)
             if nbytes == 0:
-                raise _lib.VittlesHipError("MFMA TRSM pack supports D <= %d" % _lib.SMALL_D_MAX)
+                raise _lib.VittlesHipError("MFMA TRSM pack supports D <= 8192 (got %d)" % self.D)
             self._pack = torch.empty(nbytes // 8, dtype=torch.float64, device=self.L.device)
             _lib.check(lib.vt_trsm_pack(self.L.data_ptr(), self.D, self.D, self._pack.data_ptr(),
                                         dev.stream_ptr()), "vt_trsm_pack")

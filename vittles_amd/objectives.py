@@ -108,7 +108,7 @@ class WeightedGLMObjective(RegisteredObjective):
             return self._cache
         nbytes = lib.vt_glm_hessian_workspace_bytes(self.N, self.D)
         if nbytes == 0:
-            raise _lib.VittlesHipError("vt_glm_hessian supports D <= %d (got %d)" % (_lib.SMALL_D_MAX, self.D))
+            raise _lib.VittlesHipError("vt_glm_hessian does not support D = %d" % self.D)
         if self._ws is None or self._ws.numel() * 8 < nbytes:
             self._ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=self.device)
         H = torch.empty((self.D, self.D), dtype=torch.float64, device=self.device)

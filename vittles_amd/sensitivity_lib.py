@@ -92,12 +92,12 @@ class EstimatingEquationLinearApproximation:
         self._sens_rows = None      # (N, D) row-major CUDA tensor when computed on the fast path
         self._sens_host = None
         if isinstance(jac0, LazyCrossHessian):
-            if chol is not None and chol.D <= 128:
+            if chol is not None and chol.D <= 8192:
                 # K2 + K5 fused: S[n, :] = -r_n H^{-1} x_n, jac0 never materialised.
                 self._sens_rows = chol.solve_rows(jac0.X, rowscale=jac0.r, alpha=-1.0)
             else:
                 self._sens_rows = (-1 * self._hess_solver(jac0.materialize())).t().contiguous()
-        elif chol is not None and chol.D <= 128 and _len(self._hyper_val0) >= 64:
+        elif chol is not None and chol.D <= 8192 and _len(self._hyper_val0) >= 64:
             rows = dev.to_device(jac0, chol.L.device).t().contiguous()
             self._sens_rows = chol.solve_rows(rows, alpha=-1.0)
         else:
