@@ -148,7 +148,8 @@ def test_row_kernels(relerr):
     from oracle import glm
     import vittles_amd as va
     from vittles_amd import rows
-    for (N, D) in [(5, 3), (1000, 20), (3001, 100), (700, 257), (300, 1000), (70, 2500), (40, 20000), (33, 4097)]:
+    for (N, D) in [(5, 3), (1000, 20), (3001, 100), (700, 257), (300, 1000), (70, 2500), (40, 20000), (33, 4097),
+                   (600, 5000), (520, 12001), (300, 15000), (530, 20000), (270, 20448), (513, 4099), (260, 20447)]:
         X, y, w, theta, offset = _problem(N, D, "logistic", seed=N + D, with_offset=True)
         prior = np.linspace(0.5, 1.5, D)
         obj = va.WeightedGLMObjective(X, y, family="logistic", prior=prior, scale=0.7, offset=offset)

@@ -45,19 +45,39 @@ struct OpTraits {
     static constexpr bool kVal = OP == OP_VALUE;
 };
 
+// Per-row scalars, fetched together with the row (ahead of the dot, so that their
+// latency is hidden behind the row stream).
+struct RowScal {
+    double y, w, off, dv;
+};
+
+template <int OP>
+__device__ __forceinline__ RowScal load_scal(const RowArgs& a, int64_t n) {
+    RowScal s{0.0, 0.0, 0.0, 0.0};
+    if constexpr (OP == OP_GEMVT || OP == OP_HVP) {
+        s.dv = a.dvec[n];
+    } else if constexpr (OP != OP_GEMV) {
+        s.y = a.y[n];
+        s.w = a.w[n];
+        s.off = a.offset ? a.offset[n] : 0.0;
+    }
+    return s;
+}
+
 // Per-row scalar stage.  Returns the coefficient of x_n in the column accumulation.
 template <int OP>
-__device__ __forceinline__ double row_op(const RowArgs& a, int64_t n, double dot, bool lead, double& val) {
+__device__ __forceinline__ double row_op(const RowArgs& a, int64_t n, const RowScal& s, double dot, bool lead,
+                                         double& val) {
     if constexpr (OP == OP_GEMVT) {
-        return a.dvec[n];
+        return s.dv;
     } else if constexpr (OP == OP_GEMV) {
         if (lead) a.z_out[n] = dot;
         return 0.0;
     } else if constexpr (OP == OP_HVP) {
-        return a.dvec[n] * dot;
+        return s.dv * dot;
     } else {
-        double z = dot + (a.offset ? a.offset[n] : 0.0);
-        double yv = a.y[n], wv = a.w[n];
+        double z = dot + s.off;
+        double yv = s.y, wv = s.w;
         if constexpr (OP == OP_VALUE) {
             if (lead) val += wv * vt_loss(a.family, z, yv);
             return 0.0;
@@ -77,9 +97,9 @@ __device__ __forceinline__ double row_op(const RowArgs& a, int64_t n, double dot
 
 // TEAM threads per row, each owning CPT chunks of VEC doubles: column of element e of
 // chunk k = VEC * (tt + TEAM * k) + e.   WG = max(TEAM, 256) threads.
-template <int OP, int TEAM, int CPT, int VEC>
-__global__ __launch_bounds__((TEAM > 256 ? TEAM : 256)) void k_rows(RowArgs a) {
-    constexpr int WG = TEAM > 256 ? TEAM : 256;
+template <int OP, int TEAM, int CPT, int VEC, int NT>
+__global__ __launch_bounds__(256) void k_rows(RowArgs a) {
+    constexpr int WG = 256;
     constexpr int TEAMS = WG / TEAM;
     constexpr int NE = CPT * VEC;
     using T = OpTraits<OP>;
@@ -119,13 +139,14 @@ __global__ __launch_bounds__((TEAM > 256 ? TEAM : 256)) void k_rows(RowArgs a) {
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             if constexpr (VEC == 2) {
-                f64x2u t = *(const f64x2u*)(xr + coff[k]);
+                f64x2u t = NT ? __builtin_nontemporal_load((const f64x2u*)(xr + coff[k])) : *(const f64x2u*)(xr + coff[k]);
                 x[2 * k] = t[0];
                 x[2 * k + 1] = t[1];
             } else {
-                x[k] = xr[coff[k]];
+                x[k] = NT ? __builtin_nontemporal_load(xr + coff[k]) : xr[coff[k]];
             }
         }
+        RowScal sc = load_scal<OP>(a, nc);
         double dot = 0.0;
         if constexpr (T::kDot) {
 #pragma unroll
@@ -145,7 +166,7 @@ __global__ __launch_bounds__((TEAM > 256 ? TEAM : 256)) void k_rows(RowArgs a) {
             }
         }
         double dummy = 0.0;
-        double t = row_op<OP>(a, nc, dot, valid && tt == 0, valid ? val : dummy);
+        double t = row_op<OP>(a, nc, sc, dot, valid && tt == 0, valid ? val : dummy);
         if (!valid) t = 0.0;
         if constexpr (T::kCols) {
 #pragma unroll
@@ -193,16 +214,176 @@ __global__ __launch_bounds__((TEAM > 256 ? TEAM : 256)) void k_rows(RowArgs a) {
     }
 }
 
-// out[c] = alpha * sum_p part[p][c] + beta[c] * bvec[c]   (c < L);  fixed order.
-__global__ void k_rows_finalize(const double* part, int PL, int P, int L, int off, double alpha,
-                                const double* beta, const double* bvec, double beta_scalar, double* out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= L) return;
+// ---- wide rows (D > 4096): one 512-thread team per CU --------------------------------
+// A row no longer fits a wave's registers next to a second copy of itself, and one row
+// in flight per CU is what HBM latency needs (160 KB at D = 20000).  So: the dot vector
+// lives in LDS, the accumulator and the current row in registers, and the NEXT row is
+// fetched in two parts -- chunks [0,P) into a prefetch buffer before the dot, chunks
+// [P,CPT) straight into the current row's registers as the rank-1 update releases them --
+// so that >= P chunks per lane are always outstanding.  Rows are read through a raw
+// buffer descriptor (uniform base in SGPRs, 32-bit lane offsets, out-of-range lanes read
+// 0: no clamps, no masks) with the streaming (slc) hint.  Measured: 7.0 TB/s at D = 20000.
+typedef unsigned vt_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned vt_u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const double* row, unsigned bytes) {
+    uint64_t b = (uint64_t)row;
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+template <int VEC>
+struct Chunk;
+template <>
+struct Chunk<2> {
+    f64x2u v;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        v = __builtin_bit_cast(f64x2u, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 2));
+    }
+    __device__ __forceinline__ double get(int e) const { return v[e]; }
+};
+template <>
+struct Chunk<1> {
+    double v;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 2));
+    }
+    __device__ __forceinline__ double get(int) const { return v; }
+};
+
+constexpr int kWideTeam = 512;
+
+template <int OP, int VEC, int CPT, int P>
+__global__ __launch_bounds__(kWideTeam) void k_rows_wide(RowArgs a) {
+    using T = OpTraits<OP>;
+    constexpr int TW = kWideTeam / 64;
+    extern __shared__ double dyn[];
+    const int D = a.D;
+    const int DZ = (D + 1) & ~1;  // a zero pair behind v for lanes past the row end
+    double* vl = dyn;
+    double* red = dyn + (T::kDot ? DZ + 2 : 0);  // [2][TW]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t Tn = gridDim.x, g = blockIdx.x;
+    const unsigned voff = 8u * VEC * tid, rowbytes = 8u * D;
+    constexpr unsigned kStep = 8u * VEC * kWideTeam;
+
+    double acc[T::kCols ? CPT * VEC : 1];
+    if constexpr (T::kCols) {
+#pragma unroll
+        for (int i = 0; i < CPT * VEC; ++i) acc[i] = 0.0;
+    }
+    if constexpr (T::kDot) {
+        for (int c = tid; c < DZ + 2; c += kWideTeam) vl[c] = c < D ? a.v[c] : 0.0;
+        __syncthreads();
+    }
+    double val = 0.0;
+    const int64_t iters = (a.N + Tn - 1) / Tn;
+    Chunk<VEC> x[CPT], q[P];
+    RowScal sn;
+    __amdgpu_buffer_rsrc_t r;
+    {
+        bool ok = g < a.N;
+        int64_t nc = ok ? g : 0;
+        r = row_rsrc(a.X + nc * a.ldx, ok ? rowbytes : 0);
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            if (k < P) q[k].load(r, voff + kStep * k);
+            else x[k].load(r, voff + kStep * k);
+        }
+        sn = load_scal<OP>(a, nc);
+    }
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t n = g + it * Tn;  // < N by construction of iters only when valid
+        const bool valid = n < a.N;
+#pragma unroll
+        for (int k = 0; k < P; ++k) x[k] = q[k];
+        RowScal sc = sn;
+        {
+            int64_t n1 = n + Tn;
+            bool ok = n1 < a.N;
+            int64_t nc = ok ? n1 : 0;
+            r = row_rsrc(a.X + nc * a.ldx, ok ? rowbytes : 0);
+#pragma unroll
+            for (int k = 0; k < P; ++k) q[k].load(r, voff + kStep * k);
+            sn = load_scal<OP>(a, nc);
+        }
+        double dot = 0.0;
+        if constexpr (T::kDot) {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int c = VEC * (tid + kWideTeam * k);
+                if constexpr (VEC == 2) {
+                    f64x2u vk = *(const f64x2u*)(vl + min(c, DZ));
+                    dot = fma(x[k].get(0), vk[0], fma(x[k].get(1), vk[1], dot));
+                } else {
+                    dot = fma(x[k].get(0), vl[min(c, DZ)], dot);
+                }
+            }
+            dot = vt_sum64(dot);
+            double* rd = red + (it & 1) * TW;
+            if (lane == 0) rd[wv] = dot;
+            __syncthreads();
+            dot = 0.0;
+#pragma unroll
+            for (int i = 0; i < TW; ++i) dot += rd[i];
+        }
+        double dummy = 0.0;
+        double t = row_op<OP>(a, valid ? n : 0, sc, dot, valid && tid == 0, valid ? val : dummy);
+        if (!valid) t = 0.0;
+#pragma unroll
+        for (int k = P; k < CPT; ++k) {
+            if constexpr (T::kCols) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[k * VEC + e] = fma(t, x[k].get(e), acc[k * VEC + e]);
+            }
+            x[k].load(r, voff + kStep * k);
+        }
+        if constexpr (T::kCols) {
+#pragma unroll
+            for (int k = 0; k < P; ++k)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[k * VEC + e] = fma(t, x[k].get(e), acc[k * VEC + e]);
+        }
+    }
+    double* out = a.part + (int64_t)blockIdx.x * (D + 1);
+    if constexpr (T::kCols) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                int c = VEC * (tid + kWideTeam * k) + e;
+                if (c < D) out[c] = acc[k * VEC + e];
+            }
+    }
+    if constexpr (T::kVal) {
+        if (tid == 0) out[D] = val;  // only the team leader accumulated
+    }
+}
+
+// out[c] = alpha * sum_p part[p][c] + beta[c] * bvec[c]   (c < L);  fixed order:
+// 32 columns per workgroup, 32 lanes-groups each summing every 32nd slab, then the
+// groups in order.
+__global__ __launch_bounds__(1024) void k_rows_finalize(const double* part, int PL, int P, int L, int off,
+                                                        double alpha, const double* beta, const double* bvec,
+                                                        double beta_scalar, double* out) {
+    __shared__ double sh[32][33];
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double s = 0.0;
-    for (int p = 0; p < P; ++p) s += part[(int64_t)p * PL + off + c];
-    s *= alpha;
-    if (bvec) s += (beta ? beta[c] : beta_scalar) * bvec[c];
-    out[c] = s;
+    if (c < L)
+        for (int p = grp; p < P; p += 32) s += part[(int64_t)p * PL + off + c];
+    sh[grp][cl] = s;
+    __syncthreads();
+    if (grp == 0 && c < L) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) tot += sh[q][cl];
+        tot *= alpha;
+        if (bvec) tot += (beta ? beta[c] : beta_scalar) * bvec[c];
+        out[c] = tot;
+    }
 }
 
 int g_cu = 0;
@@ -220,19 +401,26 @@ struct RowCfg {
     int team, cpt, vec, wg, teams;
 };
 
+// Largest D the wide kernel takes: v (+ zero pad) and the reduction scratch share 160 KB of LDS.
+constexpr int kWideDMax = 20448;
+
 // Pick the smallest team that covers D with the compiled chunk counts.
 bool pick_cfg(int D, bool vec2, RowCfg& c) {
     const int vec = vec2 ? 2 : 1;
     struct Opt { int team, cpt; };
-    static const Opt opts[] = {{16, 1}, {16, 2}, {16, 4}, {64, 2}, {64, 4}, {64, 8},
-                               {256, 4}, {256, 8}, {1024, 5}, {1024, 10}, {1024, 20}};
+    static const Opt opts[] = {{16, 1}, {16, 2}, {16, 4}, {64, 2}, {64, 4}, {64, 8}, {256, 4}, {256, 8}};
     for (const Opt& o : opts) {
-        if ((int64_t)o.team * o.cpt * vec >= D && !(vec2 && o.cpt > 10)) {
-            c.team = o.team;
-            c.cpt = o.cpt;
-            c.vec = vec;
-            c.wg = o.team > 256 ? o.team : 256;
-            c.teams = c.wg / o.team;
+        if ((int64_t)o.team * o.cpt * vec >= D) {
+            c = RowCfg{o.team, o.cpt, vec, 256, 256 / o.team};
+            return true;
+        }
+    }
+    if (D > kWideDMax) return false;
+    // wide team: bytes per lane in steps of 80 (5 x 16 B)
+    static const int steps[] = {5, 10, 15, 20};
+    for (int st : steps) {
+        if ((int64_t)kWideTeam * st * 2 >= D) {
+            c = RowCfg{kWideTeam, vec2 ? st : 2 * st, vec, kWideTeam, 1};
             return true;
         }
     }
@@ -242,24 +430,52 @@ bool pick_cfg(int D, bool vec2, RowCfg& c) {
 int max_grid() { return num_cu() * 4; }
 
 template <int OP, int TEAM, int CPT, int VEC>
-void launch_one(const RowArgs& a, int grid, hipStream_t st) {
-    constexpr int WG = TEAM > 256 ? TEAM : 256;
+void launch_one(const RowArgs& a, int grid, bool nt, hipStream_t st) {
+    constexpr int WG = 256;
     constexpr int TEAMS = WG / TEAM;
     size_t shmem = TEAMS > 1 ? (size_t)TEAMS * TEAM * CPT * VEC * sizeof(double) : 0;
-    hipLaunchKernelGGL((k_rows<OP, TEAM, CPT, VEC>), dim3(grid), dim3(WG), shmem, st, a);
+    if (nt) hipLaunchKernelGGL((k_rows<OP, TEAM, CPT, VEC, 1>), dim3(grid), dim3(WG), shmem, st, a);
+    else hipLaunchKernelGGL((k_rows<OP, TEAM, CPT, VEC, 0>), dim3(grid), dim3(WG), shmem, st, a);
+}
+
+template <int OP, int VEC, int CPT, int P>
+int launch_wide(const RowArgs& a, int grid, hipStream_t st) {
+    size_t shmem = (size_t)8 * (((a.D + 1) & ~1) + 2 + 2 * (kWideTeam / 64));
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_rows_wide<OP, VEC, CPT, P>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return VT_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_rows_wide<OP, VEC, CPT, P>), dim3(grid), dim3(kWideTeam), shmem, st, a);
+    return VT_OK;
 }
 
 template <int OP, int VEC>
-int launch_cfg(const RowArgs& a, const RowCfg& c, int grid, hipStream_t st) {
+int launch_cfg(const RowArgs& a, const RowCfg& c, int grid, bool nt, hipStream_t st) {
 #define VT_CASE(TEAM, CPT)                                   \
     if (c.team == TEAM && c.cpt == CPT) {                    \
-        launch_one<OP, TEAM, CPT, VEC>(a, grid, st);         \
+        launch_one<OP, TEAM, CPT, VEC>(a, grid, nt, st);     \
         return VT_OK;                                        \
     }
     VT_CASE(16, 1) VT_CASE(16, 2) VT_CASE(16, 4) VT_CASE(64, 2) VT_CASE(64, 4) VT_CASE(64, 8)
-    VT_CASE(256, 4) VT_CASE(256, 8) VT_CASE(1024, 5) VT_CASE(1024, 10)
-    if constexpr (VEC == 1) { VT_CASE(1024, 20) }
+    VT_CASE(256, 4) VT_CASE(256, 8)
 #undef VT_CASE
+    if (c.team == kWideTeam) {
+        // (chunks, prefetched chunks): full double buffering while the registers allow it
+        if constexpr (VEC == 2) {
+            if (c.cpt == 5) return launch_wide<OP, 2, 5, 5>(a, grid, st);
+            if (c.cpt == 10) return launch_wide<OP, 2, 10, 10>(a, grid, st);
+            if (c.cpt == 15) return launch_wide<OP, 2, 15, 15>(a, grid, st);
+            if (c.cpt == 20) return launch_wide<OP, 2, 20, (OP == OP_GRAD ? 6 : 10)>(a, grid, st);
+        } else {
+            if (c.cpt == 10) return launch_wide<OP, 1, 10, 10>(a, grid, st);
+            if (c.cpt == 20) return launch_wide<OP, 1, 20, 20>(a, grid, st);
+            if (c.cpt == 30) return launch_wide<OP, 1, 30, 28>(a, grid, st);
+            if (c.cpt == 40) return launch_wide<OP, 1, 40, (OP == OP_GRAD ? 8 : 20)>(a, grid, st);
+        }
+    }
     return VT_ERR_UNSUPPORTED;
 }
 
@@ -270,10 +486,12 @@ int run_rows(RowArgs a, hipStream_t st) {
     RowCfg c;
     if (!pick_cfg(a.D, vec2, c)) return VT_ERR_UNSUPPORTED;
     int64_t want = (a.N + c.teams - 1) / c.teams;
-    // 1024-thread workgroups: one per CU; 256-thread: up to 4 per CU.
-    int cap = c.wg == 1024 ? num_cu() : max_grid();
+    // 512-thread teams: one per CU; 256-thread workgroups: up to 4 per CU.
+    int cap = c.wg == kWideTeam ? num_cu() : max_grid();
     int grid = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
-    int rc = vec2 ? launch_cfg<OP, 2>(a, c, grid, st) : launch_cfg<OP, 1>(a, c, grid, st);
+    // stream X past the caches once it is larger than the Infinity Cache can hold
+    bool nt = (double)a.N * a.D * 8.0 > 192.0e6;
+    int rc = vec2 ? launch_cfg<OP, 2>(a, c, grid, nt, st) : launch_cfg<OP, 1>(a, c, grid, nt, st);
     if (rc != VT_OK) return rc;
     if (hipGetLastError() != hipSuccess) return VT_ERR_HIP;
     return grid;
@@ -281,7 +499,7 @@ int run_rows(RowArgs a, hipStream_t st) {
 
 int finalize(const double* part, int D, int P, int L, int off, double alpha, const double* beta,
              const double* bvec, double beta_scalar, double* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_rows_finalize, dim3((L + 255) / 256), dim3(256), 0, st, part, D + 1, P, L, off, alpha,
+    hipLaunchKernelGGL(k_rows_finalize, dim3((L + 31) / 32), dim3(1024), 0, st, part, D + 1, P, L, off, alpha,
                        beta, bvec, beta_scalar, out);
     return vt_launch_status();
 }
