@@ -27,7 +27,10 @@ def _problem(N, D, family, seed, prior=1.0, with_offset=False):
 
 
 @pytest.mark.parametrize("N,D", [(1, 1), (3, 5), (17, 16), (1000, 20), (257, 31), (4099, 32),
-                                 (2000, 100), (513, 128), (1001, 97), (300, 113)])
+                                 (2000, 100), (513, 128), (1001, 97), (300, 113),
+                                 # N >= 4096: the LDS-tile kernel (48-row tiles, ragged last tile, NB = 4..7)
+                                 (4096, 50), (4099, 64), (5003, 77), (4801, 96), (20001, 100), (12289, 112),
+                                 (4100, 99), (5000, 128)])
 @pytest.mark.parametrize("family", ["logistic", "poisson", "gaussian"])
 def test_fused_hessian_grad(N, D, family, relerr):
     from oracle import glm

@@ -30,14 +30,21 @@ __device__ __forceinline__ f64x4 mfma_f64(double a, double b, f64x4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global
+// memory (s_waitcnt vmcnt(0)), which drains every prefetch in flight -- fatal inside a
+// software-pipelined loop.
+__device__ __forceinline__ void vt_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ int vt_nblocks(int D) { return (D + 15) >> 4; }
 
 // v + (v rotated right by N lanes inside each row of 16 lanes), on the VALU (DPP row_ror):
 // ~10x lower latency than the ds_bpermute a __shfl_xor costs.
 template <int N>
 __device__ __forceinline__ double vt_ror16_add(double v) {
-    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, false);
-    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, true);
     return v + __hiloint2double(hi, lo);
 }
 
@@ -58,17 +65,45 @@ __device__ __forceinline__ double vt_rcp(double y) {
     return x;
 }
 
+// exp(x) in fp64 (<= 1 ulp: range reduction by ln2 in two pieces + degree-11 minimax
+// polynomial + ldexp; overflow -> inf and underflow -> 0 come out of v_ldexp_f64).
+// The coefficients sit in constant memory so that they are scalar-loaded into SGPRs:
+// libm's exp() makes hipcc park 10 of them in VGPR pairs for the whole kernel, which the
+// MFMA kernels cannot afford.
+__constant__ double kVtExpC[14] = {
+    1.4426950408889634,        // log2(e)
+    -0.6931471805599453,       // -ln2 (high part)
+    -2.3190468138462996e-17,   // -ln2 (low part)
+    0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22, 0x1.71dee623fde64p-19, 0x1.a01997c89e6b0p-16,
+    0x1.a01a014761f6ep-13, 0x1.6c16c1852b7b0p-10, 0x1.1111111122322p-7, 0x1.55555555502a1p-5,
+    0x1.5555555555511p-3, 0x1.000000000000bp-1, 1.0};
+
+__device__ __forceinline__ double vt_exp(double x) {
+    const double* C = kVtExpC;
+    double n = __builtin_rint(x * C[0]);
+    double r = fma(n, C[1], x);
+    r = fma(n, C[2], r);
+    double p = fma(r, C[3], C[4]);
+#pragma unroll
+    for (int i = 5; i <= 12; ++i) p = fma(r, p, C[i]);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    // |x| beyond the fp64 exponent range: keep n representable for the int conversion
+    n = fmin(fmax(n, -2200.0), 2200.0);
+    return ldexp(p, (int)n);
+}
+
 // Per-row link derivatives: l1 = ell'(z), l2 = ell''(z).
 __device__ __forceinline__ void vt_link(int family, double z, double y, double& l1, double& l2) {
     if (family == VT_FAMILY_LOGISTIC) {
         // p = sigmoid(z), evaluated on the stable side
-        double e = exp(-fabs(z));
+        double e = vt_exp(-fabs(z));
         double inv = vt_rcp(1.0 + e);   // 1 + e in (1, 2]: no overflow / denormal cases
         double p = z >= 0.0 ? inv : e * inv;
         l1 = p - y;
         l2 = e * inv * inv;  // p (1 - p) without cancellation
     } else if (family == VT_FAMILY_POISSON) {
-        double e = exp(z);
+        double e = vt_exp(z);
         l1 = e - y;
         l2 = e;
     } else {

@@ -16,6 +16,11 @@
 // slots beside the MFMAs.  Partials are reduced deterministically (no fp64
 // atomics): 4 waves -> 1 through LDS, then a fixed-order tree over workgroups.
 #include "vt_common.h"
+#include <cstdlib>
+#include <type_traits>
+#ifndef VT_ABL
+#define VT_ABL 0   // dev-only compile-time ablation mask (tools/build_abl.cmd)
+#endif
 
 namespace {
 
@@ -35,6 +40,7 @@ struct HessArgs {
     double* part;       // [gridDim.x][L] partial slabs, L = NBT*256 + NB*16
     double* wave_part;  // [gridDim.x][4][NBT*256] per-wave slabs
     double* sink;       // 1024 doubles nobody reads
+    int ablate;         // dev only (VT_HESS_ABLATE): 1 = no MFMA phase, 2 = no global loads
 };
 
 // Loads are UNCONDITIONAL with clamped row / column indices (a per-element
@@ -236,6 +242,295 @@ __global__ __launch_bounds__(512) void k_glm_hess_small(HessArgs a) {
         out[NBT * 256 + t] = (gl[t] + gl[NB * 16 + t]) + (gl[2 * NB * 16 + t] + gl[3 * NB * 16 + t]);
 }
 
+// ---------------------------------------------------------------------------------------
+// Tile kernel (the one that runs for N >= kTileMinRows): 12 waves per CU share TR-row tiles
+// of X through LDS.
+//
+// What shapes it (measured on MI355X, tools/micro/mfma_valu_overlap.hip): v_mfma_f64_16x16x4
+// occupies the SIMD's VALU issue for its whole 64 cycles -- three waves of independent MFMAs
+// reach 99 % of the 78.6 TFLOP/s peak, but every VALU instruction of ANY wave on that SIMD
+// adds its own cycles on top (nothing rides "beside" an fp64 MFMA).  So the kernel minimises
+// the VALU instructions executed per MFMA, and keeps every memory operation off the VALU:
+//   * X goes HBM -> LDS by buffer_load_dwordx4 ... lds (one instruction per row, no
+//     registers, no ds_write; padding columns are zero-filled by the descriptor's range
+//     check), two periods ahead of its use, three tile buffers in rotation.
+//   * wave (Q, ks) owns a QUARTER of the block triangle (7 accumulators at D = 100) and
+//     multiplies k-steps ks, ks+3, ... of the tile; A and B operands are ds_read_b64's of
+//     the tile (row stride = 16 mod 32 doubles: conflict free), B scaled by d_n on the way.
+//   * the three waves of a quarter (one SIMD) rotate through three roles, period by period:
+//       FETCH  issues the DMA of its SIMD's rows of tile p+2, then 5 of the 12 k-steps;
+//       LINK   (last period's FETCH wave: it waits for its own DMA only) computes the link of
+//              those rows of tile p+1 -- row dot by DPP; exp, rcp, ... ONCE per row, one lane
+//              per row; gradient; per-row outputs; d_n -> LDS -- then 2 k-steps;
+//       PLAIN  5 k-steps.
+//   period p:  FETCH: DMA(p+2) -> buf[(p+2)%3] | LINK: link(p+1) | all: MFMA(p) from buf[p%3] | barrier
+// ---------------------------------------------------------------------------------------
+typedef unsigned vt_u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* vt_ldsptr;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const double* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+
+constexpr int kTileThreads = 768;
+constexpr int kTileWaves = 12;
+constexpr int kTileNQ = 4;                     // owners of the block triangle
+constexpr int kTileNK = kTileWaves / kTileNQ;  // 3 waves share a quarter and split the k-steps
+constexpr int kTileMinRows = 4096;
+
+__host__ __device__ constexpr int tile_rs(int NB) { return (NB & 1) ? 16 * NB : 16 * NB + 16; }
+__host__ __device__ constexpr int tile_rows(int NB) { return NB <= 7 ? 48 : 36; }   // 3 buffers must fit 160 KB
+// blocks in bottom-row-first order; consecutive runs of that order go to the NQ owners
+__host__ __device__ constexpr int blk_ord(int NB, int i, int j) { return (NB * (NB + 1) - (i + 1) * (i + 2)) / 2 + j; }
+__host__ __device__ constexpr int blk_owner(int NB, int NQ, int i, int j) {
+    return blk_ord(NB, i, j) * NQ / (NB * (NB + 1) / 2);
+}
+__host__ __device__ constexpr int own_first(int NB, int NQ, int Q) { return (Q * (NB * (NB + 1) / 2) + NQ - 1) / NQ; }
+
+template <int NB>
+struct TileLds {   // offsets in doubles
+    static constexpr int RS = tile_rs(NB);
+    static constexpr int TR = tile_rows(NB);
+    static constexpr int kTile = 0;                       // [3][TR][RS]
+    static constexpr int kD = 3 * TR * RS;                // [3][TR]  d_n of the tile
+    static constexpr int kTheta = kD + 3 * TR;            // [NB*16]
+    static constexpr int kScratch = kTheta + NB * 16;     // [4 SIMDs][32]: z and w_n r_n of the duty wave's rows
+    static constexpr int kTotal = kScratch + 4 * 32;
+};
+
+template <int NB, int FAM, bool HAS_OFF, int Q>
+__device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, int64_t mine) {
+    using LY = TileLds<NB>;
+    constexpr int NQ = kTileNQ, NK = kTileNK, RS = LY::RS, TR = LY::TR;
+    constexpr int NBT = NB * (NB + 1) / 2;
+    constexpr int FIRST = own_first(NB, NQ, Q);
+    constexpr int NOWN = own_first(NB, NQ, Q + 1) - FIRST;
+    constexpr int RPS = TR / 4;                        // rows a duty wave links (one wave per SIMD)
+    constexpr int PASSES = (RPS + 3) / 4;
+    constexpr int CH = RS / 2;                         // 16-byte chunks per LDS row
+    constexpr int DMAH = (CH + 63) / 64;               // DMA instructions per row
+    static_assert(TR % kTileWaves == 0 && TR % 4 == 0 && (TR / 4) % NK == 0, "tile shape");
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, c = lane & 15;
+    const int simd = wid & 3, grp = wid >> 2;           // simd == Q; the roles rotate over grp
+    const double* th = lds + LY::kTheta;
+    double* zs = lds + LY::kScratch + simd * 32;
+    // scalar stage of the link: lane t < RPS owns row RPS*simd + t
+    const int trow = RPS * simd + (lane & 15);
+    const bool tlane = lane < RPS;
+
+    f64x4 acc[NOWN > 0 ? NOWN : 1];
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    double gacc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) gacc[b] = 0.0;
+
+    auto tile_first_row = [&](int64_t k) { return (blockIdx.x + k * (int64_t)gridDim.x) * (int64_t)TR; };
+    auto tile_nrow = [&](int64_t k) -> int {
+        const int64_t left = (k >= 0 && k < mine) ? a.N - tile_first_row(k) : 0;
+        return (int)(left < TR ? (left > 0 ? left : 0) : TR);
+    };
+    // the RPS rows of my SIMD of tile k -> buffer `buf`.  One descriptor per row (SALU only):
+    // lanes past the row's D doubles and rows past N read 0, and the only VGPR is 16 * chunk.
+    auto dma = [&](int64_t k, int buf) {
+        const int nrow = (VT_ABL & 2) ? 0 : tile_nrow(k);
+        const int64_t rb = nrow > 0 ? tile_first_row(k) : 0;
+        const double* xb = a.X + (rb + RPS * simd) * a.ldx;
+#pragma unroll
+        for (int rr = 0; rr < RPS; ++rr) {
+            const int row = RPS * simd + rr;
+            __amdgpu_buffer_rsrc_t xrs = tile_rsrc(xb + (int64_t)rr * a.ldx, row < nrow ? 8u * a.D : 0u);
+            double* dst = lds + LY::kTile + buf * (TR * RS) + row * RS;
+#pragma unroll
+            for (int h = 0; h < DMAH; ++h) {
+                const int chunk = 64 * h + lane;
+                if (chunk < CH)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (vt_ldsptr)(dst + 128 * h), 16, 16u * chunk, 0, 0, 0);
+            }
+        }
+    };
+    auto mfma_part = [&](int buf, int kfirst, auto count) {
+        constexpr int CNT = decltype(count)::value;
+        if (!(VT_ABL & 1)) {
+            const double* tb = lds + LY::kTile + buf * (TR * RS) + (q + 4 * kfirst) * RS + c;
+            const double* db = lds + LY::kD + buf * TR + q + 4 * kfirst;
+#pragma unroll
+            for (int m = 0; m < CNT; ++m) {
+                double xa[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) xa[b] = tb[4 * m * RS + 16 * b];
+                const double dq = db[4 * m];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const double bj = dq * xa[j];
+#pragma unroll
+                    for (int i = j; i < NB; ++i)
+                        if (blk_owner(NB, NQ, i, j) == Q)
+                            acc[blk_ord(NB, i, j) - FIRST] = mfma_f64(xa[i], bj, acc[blk_ord(NB, i, j) - FIRST]);
+                }
+                // one k-step's operands at a time: deeper operand prefetch (tried: double-buffered
+                // xa) makes hipcc spill the accumulators around the role branches
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // Link of the RPS rows [RPS*simd, RPS*(simd+1)) of tile k (in buffer `buf`).
+    double sy = 0.0, sw = 0.0, soff = 0.0;
+    auto load_scal = [&](int64_t k) {
+        const int nrow = tile_nrow(k);
+        const int64_t rb = nrow > 0 ? tile_first_row(k) : 0;
+        const unsigned ro = tlane ? 8u * trow : 0xfffffff0u;
+        sy = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tile_rsrc(a.y + rb, 8u * nrow), ro, 0, 0));
+        sw = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tile_rsrc(a.w + rb, 8u * nrow), ro, 0, 0));
+        if (HAS_OFF)
+            soff = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tile_rsrc(a.offset + rb, 8u * nrow), ro, 0, 0));
+    };
+    auto link = [&](int64_t k, int buf) {
+        const int nrow = tile_nrow(k);
+        const int64_t rb = nrow > 0 ? tile_first_row(k) : 0;
+        double x[PASSES][NB];
+        // stage 1: z_n = x_n . theta (16 lanes per row)
+#pragma unroll
+        for (int k2 = 0; k2 < PASSES; ++k2) {
+            const int rl = min(4 * k2 + q, RPS - 1);
+            const double* tr = lds + LY::kTile + buf * (TR * RS) + (RPS * simd + rl) * RS + c;
+            double pz = 0.0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                x[k2][b] = tr[16 * b];
+                pz = fma(x[k2][b], th[16 * b + c], pz);
+            }
+            const double z = vt_sum16_dpp(pz);
+            if (c == 0) zs[4 * k2 + q] = z;
+        }
+        // stage 2: the scalar chain, one lane per row
+        {
+            double z = zs[lane & 15];
+            if (HAS_OFF) z += soff;
+            double l1, l2;
+            vt_link(FAM, z, sy, l1, l2);
+            const bool rowok = tlane && trow < nrow;
+            const double rr = a.scale * l1;
+            const double dw = rowok ? a.scale * sw * l2 : 0.0;
+            const double gwt = rowok ? sw * rr : 0.0;
+            const unsigned so = tlane ? 8u * trow : 0xfffffff0u;    // other lanes: dropped by the range check
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(vt_u32x2, rr),
+                                                  tile_rsrc(a.r_out + rb, a.r_out ? 8u * nrow : 0u), so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(vt_u32x2, dw),
+                                                  tile_rsrc(a.d_out + rb, a.d_out ? 8u * nrow : 0u), so, 0, 0);
+            if (tlane) lds[LY::kD + buf * TR + trow] = dw;
+            if (lane < 16) zs[16 + lane] = gwt;
+        }
+        // stage 3: gradient
+#pragma unroll
+        for (int k2 = 0; k2 < PASSES; ++k2) {
+            const double gwt = (4 * k2 + q < RPS) ? zs[16 + 4 * k2 + q] : 0.0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) gacc[b] = fma(gwt, x[k2][b], gacc[b]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // k-steps of a tile: KD for the LINK wave, KO for each of the other two
+    constexpr int KSTEPS = TR / 4;
+    constexpr int KD = KSTEPS == 12 ? 2 : 1;
+    constexpr int KO = (KSTEPS - KD) / 2;
+    static_assert(KD + 2 * KO == KSTEPS, "k-step split");
+    // prologue: group 0 fetches tile 0
+    if (grp == 0) {
+        dma(0, 0);
+        load_scal(0);
+    }
+    int b0 = 2;                        // buffer of tile p (p = -1: unused)
+    int role = grp;                    // 0: LINK, 1: FETCH, 2: PLAIN in this period
+    for (int64_t p = -1; p < mine; ++p) {
+        const int b1 = b0 == 2 ? 0 : b0 + 1;           // buffer of tile p+1
+        const int b2 = b1 == 2 ? 0 : b1 + 1;           // buffer of tile p+2
+        if (role == 1 && !(VT_ABL & 8)) {
+            dma(p + 2, b2);
+            load_scal(p + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (p >= 0) mfma_part(b0, KD, std::integral_constant<int, KO>());
+        } else if (role == 0 && !(VT_ABL & 4)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my own DMA of tile p+1 (issued a period ago)
+            link(p + 1, b1);
+            if (p >= 0) mfma_part(b0, 0, std::integral_constant<int, KD>());
+        } else {
+            if (p >= 0) mfma_part(b0, role == 2 ? KD + KO : (role == 1 ? KD : 0), std::integral_constant<int, KO>());
+        }
+        vt_lds_barrier();
+        b0 = b1;
+        role = role == 0 ? 2 : role - 1;               // FETCH -> LINK -> PLAIN -> FETCH
+    }
+    __syncthreads();   // every tile is dead
+
+    // ---- gradient: the 4 row groups of the wave, one slot per wave -----------------------------
+    double* hl = lds;               // [NBT*256]
+    double* gl = lds + NBT * 256;   // [kTileWaves][NB*16]
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        double v = gacc[b];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (q == 0) gl[wid * (NB * 16) + 16 * b + c] = v;
+    }
+    // ---- H: the NK waves of a quarter add up in LDS in the order ks = 0, 1, 2 --------------------
+#pragma unroll
+    for (int turn = 0; turn < NK; ++turn) {
+        if (grp == turn) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j)
+                    if (blk_owner(NB, NQ, i, j) == Q) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            double* e = hl + (vt_tri(i, j) * 4 + r) * 64 + lane;
+                            const double v = acc[blk_ord(NB, i, j) - FIRST][r];
+                            *e = turn == 0 ? v : *e + v;
+                        }
+                    }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NB, int FAM, bool HAS_OFF>
+__global__ __launch_bounds__(kTileThreads) void k_glm_hess_tile(HessArgs a) {
+    using LY = TileLds<NB>;
+    constexpr int NBT = NB * (NB + 1) / 2;
+    constexpr int L = NBT * 256 + NB * 16;
+    extern __shared__ double lds[];
+    for (int t = threadIdx.x; t < NB * 16; t += kTileThreads) lds[LY::kTheta + t] = t < a.D ? a.theta[t] : 0.0;
+    for (int t = threadIdx.x; t < 4 * 32; t += kTileThreads) lds[LY::kScratch + t] = 0.0;
+    __syncthreads();
+    const int64_t ntiles = (a.N + LY::TR - 1) / LY::TR;
+    const int64_t mine = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3) {   // quarter = SIMD
+        case 0: hess_tile_body<NB, FAM, HAS_OFF, 0>(a, lds, mine); break;
+        case 1: hess_tile_body<NB, FAM, HAS_OFF, 1>(a, lds, mine); break;
+        case 2: hess_tile_body<NB, FAM, HAS_OFF, 2>(a, lds, mine); break;
+        default: hess_tile_body<NB, FAM, HAS_OFF, 3>(a, lds, mine); break;
+    }
+    double* out = a.part + (int64_t)blockIdx.x * L;
+    for (int e = threadIdx.x; e < NBT * 256; e += kTileThreads) out[e] = lds[e];
+    for (int t = threadIdx.x; t < NB * 16; t += kTileThreads) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kTileWaves; ++w) s += lds[NBT * 256 + w * (NB * 16) + t];
+        out[NBT * 256 + t] = s;
+    }
+}
+
+inline size_t tile_lds_bytes(int NB) {
+    const size_t loop = (size_t)3 * tile_rows(NB) * tile_rs(NB) + 3 * tile_rows(NB) + NB * 16 + 4 * 32;
+    const size_t tail = (size_t)NB * (NB + 1) / 2 * 256 + kTileWaves * NB * 16;
+    return std::max(loop, tail) * sizeof(double);
+}
+
 // Sum `per` consecutive partial slabs into one: out[p][e] = sum_{k<per} in[p*per + k][e].
 __global__ void k_reduce_slabs(const double* in, double* out, int L, int P_in, int per) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -309,6 +604,35 @@ void launch_hess_small2(const HessArgs& a, int grid, hipStream_t st) {
         hipLaunchKernelGGL((k_glm_hess_small<NB, FAM, false>), dim3(grid), dim3(512), 0, st, a);
 }
 
+template <int NB, int FAM, bool HAS_OFF>
+int launch_hess_tile3(const HessArgs& a, int grid, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_glm_hess_tile<NB, FAM, HAS_OFF>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return VT_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_glm_hess_tile<NB, FAM, HAS_OFF>), dim3(grid), dim3(kTileThreads), tile_lds_bytes(NB), st, a);
+    return VT_OK;
+}
+
+template <int NB>
+int launch_hess_tile(const HessArgs& a, int grid, hipStream_t st) {
+    const bool off = a.offset != nullptr;
+    switch (a.family) {
+        case VT_FAMILY_LOGISTIC:
+            return off ? launch_hess_tile3<NB, VT_FAMILY_LOGISTIC, true>(a, grid, st)
+                       : launch_hess_tile3<NB, VT_FAMILY_LOGISTIC, false>(a, grid, st);
+        case VT_FAMILY_POISSON:
+            return off ? launch_hess_tile3<NB, VT_FAMILY_POISSON, true>(a, grid, st)
+                       : launch_hess_tile3<NB, VT_FAMILY_POISSON, false>(a, grid, st);
+        default:
+            return off ? launch_hess_tile3<NB, VT_FAMILY_GAUSSIAN, true>(a, grid, st)
+                       : launch_hess_tile3<NB, VT_FAMILY_GAUSSIAN, false>(a, grid, st);
+    }
+}
+
 template <int NB>
 void launch_hess_small(const HessArgs& a, int grid, hipStream_t st) {
     switch (a.family) {
@@ -360,14 +684,28 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
     }
     const int NB = (D + 15) / 16;
     const int L = slab_len(NB);
-    const int grid = hess_grid(N);
+    const bool tiled = N >= kTileMinRows && NB >= 4 && NB <= 7 && (ldx % 2 == 0) && ((uintptr_t)X % 16 == 0) &&
+                       !getenv("VT_HESS_NO_TILE");
+    const int64_t ntiles = (N + tile_rows(NB) - 1) / tile_rows(NB);
+    const int grid = tiled ? (int)std::min<int64_t>(ntiles, num_cu()) : hess_grid(N);
     double* part = (double*)ws;
     double* part2 = part + (size_t)num_cu() * L;
     double* wave_part = part2 + (size_t)kStage2 * L;
     double* sink = wave_part + (size_t)num_cu() * 4 * (NB * (NB + 1) / 2) * 256;
 
-    HessArgs a{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, wave_part, sink};
-    switch (NB) {
+    static const int ablate = getenv("VT_HESS_ABLATE") ? atoi(getenv("VT_HESS_ABLATE")) : 0;
+    HessArgs a{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, wave_part, sink, ablate};
+    if (tiled) {
+        int rc = VT_ERR_UNSUPPORTED;
+        switch (NB) {
+            case 4: rc = launch_hess_tile<4>(a, grid, st); break;
+            case 5: rc = launch_hess_tile<5>(a, grid, st); break;
+            case 6: rc = launch_hess_tile<6>(a, grid, st); break;
+            case 7: rc = launch_hess_tile<7>(a, grid, st); break;
+            case 8: rc = launch_hess_tile<8>(a, grid, st); break;
+        }
+        if (rc != VT_OK) return rc;
+    } else switch (NB) {
         case 1: launch_hess_small<1>(a, grid, st); break;
         case 2: launch_hess_small<2>(a, grid, st); break;
         case 3: launch_hess_small<3>(a, grid, st); break;
