@@ -12,6 +12,7 @@
 //                 small-TRSM solve with the block's inverted-diagonal pack.
 // Replaces the same reference lines as the small-D kernels (see include/vittles_hip.h).
 #include "vt_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -119,11 +120,131 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a) {
         }
 }
 
+// ------------------------------------------------------------------ LDS-staged kernels -------
+// Same products, operands staged through LDS by buffer_load_dwordx4 ... lds (no registers, no VALU:
+// VALU instructions are not free next to fp64 MFMAs, tools/micro/mfma_valu_overlap.hip), three
+// stages of 16 k in rotation, 8 waves (2 per SIMD) of 64x32 accumulators per 128x128 tile.
+typedef __attribute__((address_space(3))) void* vt_ldsptr;
+constexpr int kKC = 16;                        // k per stage
+constexpr int kStages = 3;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rsrc(const double* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void lg_wait4_barrier() {
+    // the stage about to be used has landed (only the newest 4 DMA instructions of this wave may
+    // still be in flight), then everybody's part of it
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// C = beta C + alpha A B^T.  LDS panel layout [k/2][row][2]: one DMA instruction moves (64 rows) x
+// (2 k) and MFMA operand reads (lane = row, k) are bank-conflict free.
+template <bool LOWER>
+__global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
+    if (LOWER && blockIdx.y > blockIdx.x) return;
+    extern __shared__ double lds[];            // [kStages][A: 8 planes x 128 rows x 2 | B: same]
+    constexpr int PANEL = (kKC / 2) * kT * 2;  // 2048 doubles
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;   // 2 x 4 waves of 64 x 32
+    const int q = lane >> 4, c = lane & 15;
+    const int64_t m0 = (int64_t)blockIdx.x * kT;
+    const int n0 = blockIdx.y * kT;
+    const int mrem = (int)min((int64_t)kT, a.M - m0), nrem = min(kT, a.N - n0);
+    const int nk = (a.K + kKC - 1) / kKC;
+
+    // this wave's 4 DMA instructions of a stage: ids wave*4 .. wave*4+3 of 32 (16 for A, 16 for B)
+    auto issue = [&](int t, int buf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int id = wave * 4 + e;
+            const bool isb = id >= 16;
+            const int kp = (id & 15) >> 1, half = id & 1;
+            const int k0 = t * kKC + 2 * kp;
+            const int rem = isb ? nrem : mrem;
+            const int64_t ld = isb ? a.ldb : a.lda;
+            const double* base = (isb ? a.B + (int64_t)n0 * a.ldb : a.A + m0 * a.lda) + k0;
+            // rows past the tile and k past K read 0
+            const unsigned bytes = (t < nk && k0 < a.K) ? (unsigned)(((int64_t)(rem - 1) * ld + 2) * 8) : 0u;
+            double* dst = lds + buf * (2 * PANEL) + (isb ? PANEL : 0) + kp * (kT * 2) + half * 128;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(lg_rsrc(base, bytes), (vt_ldsptr)dst, 16,
+                                                     (unsigned)((64 * half + lane) * ld) * 8u, 0, 0, 0);
+        }
+    };
+
+    f64x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+    issue(0, 0);
+    issue(1, 1);
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+        lg_wait4_barrier();
+        const int b2 = buf == 0 ? 2 : buf - 1;     // (buf + 2) % 3
+        issue(t + 2, b2);
+        const double* pa = lds + buf * (2 * PANEL) + (q >> 1) * (kT * 2) + (64 * wm + c) * 2 + (q & 1);
+        const double* pb = lds + buf * (2 * PANEL) + PANEL + (q >> 1) * (kT * 2) + (32 * wn + c) * 2 + (q & 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            double af[4], bf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = pa[2 * s * (kT * 2) + 32 * i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = pb[2 * s * (kT * 2) + 32 * j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-filled look-ahead stages
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 32 * wn + 16 * j + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + 64 * wm + 16 * i + q + 4 * r;
+                if (m < a.M && n < a.N) {
+                    double* p = a.C + m * a.ldc + n;
+                    double v = a.alpha * acc[i][j][r];
+                    if (a.beta != 0.0) v = fma(a.beta, *p, v);
+                    *p = v;
+                }
+            }
+        }
+}
+
+bool lds_path_ok(const double* A, int64_t lda, const double* B, int64_t ldb, int K) {
+    return K % 2 == 0 && lda % 2 == 0 && ldb % 2 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
+           !getenv("VT_LARGE_NO_LDS");
+}
+
 int gemm_nt(double* C, int64_t ldc, int64_t M, int N, const double* A, int64_t lda, const double* B,
             int64_t ldb, int K, double alpha, double beta, bool lower, hipStream_t st) {
     if (M <= 0 || N <= 0) return VT_OK;
     GemmArgs a{C, ldc, M, N, A, lda, B, ldb, K, alpha, beta};
     dim3 grid((unsigned)((M + kT - 1) / kT), (unsigned)((N + kT - 1) / kT));
+    if (lds_path_ok(A, lda, B, ldb, K)) {
+        const size_t shmem = (size_t)kStages * 2 * (kKC / 2) * kT * 2 * sizeof(double);   // 96 KB
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)k_gemm_nt_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)shmem) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_gemm_nt_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)shmem) != hipSuccess)
+                return VT_ERR_HIP;
+            attr_set = true;
+        }
+        if (lower) hipLaunchKernelGGL((k_gemm_nt_lds<true>), grid, dim3(512), shmem, st, a);
+        else hipLaunchKernelGGL((k_gemm_nt_lds<false>), grid, dim3(512), shmem, st, a);
+        return vt_launch_status();
+    }
     bool vec = (K % 4 == 0) && K >= 4;
     if (vec && lower) hipLaunchKernelGGL((k_gemm_nt<true, true>), grid, dim3(256), 0, st, a);
     else if (vec) hipLaunchKernelGGL((k_gemm_nt<true, false>), grid, dim3(256), 0, st, a);
@@ -222,6 +343,99 @@ __global__ __launch_bounds__(256) void k_syrk_tile(SyrkArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 out[(wm * 64 + 16 * i + q + 4 * r) * kT + wn * 64 + 16 * j + c] = acc[i][j][r];
+}
+
+// LDS-staged version: panels [n][col] (row stride 144 doubles = 16 mod 32: conflict-free operand
+// reads), one DMA instruction per row of a panel, d_n fetched a stage ahead.
+__global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
+    extern __shared__ double lds[];            // [kStages][I: 16 x 144 | J: 16 x 144]
+    constexpr int RSTR = kT + 16, PANEL = kKC * RSTR;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int q = lane >> 4, c = lane & 15;
+    int t_id = blockIdx.x, ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t_id) ++ti;
+    const int tj = t_id - ti * (ti + 1) / 2;
+    const int ntl = a.nt * (a.nt + 1) / 2;
+    double* out = a.part + ((int64_t)blockIdx.y * ntl + t_id) * (kT * kT);
+    const bool skip = ti == tj && 32 * wn >= 64 * (wm + 1);   // sub-tile strictly above the diagonal
+
+    int64_t per = (a.N + a.ksplit - 1) / a.ksplit;
+    per = (per + kKC - 1) / kKC * kKC;
+    const int64_t r0 = (int64_t)blockIdx.y * per;
+    const int64_t r1 = min(a.N, r0 + per);
+    const int nk = r1 > r0 ? (int)((r1 - r0 + kKC - 1) / kKC) : 0;
+    const int icols = min(kT, a.D - ti * kT), jcols = min(kT, a.D - tj * kT);
+
+    auto issue = [&](int t, int buf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int id = wave * 4 + e;
+            const bool isj = id >= 16;
+            const int n = id & 15;
+            const int64_t row = r0 + (int64_t)t * kKC + n;
+            const bool ok = t < nk && row < r1;
+            const double* base = a.X + (ok ? row : 0) * a.ldx + (isj ? tj : ti) * kT;
+            const unsigned bytes = ok ? 8u * (isj ? jcols : icols) : 0u;
+            double* dst = lds + buf * (2 * PANEL) + (isj ? PANEL : 0) + n * RSTR;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(lg_rsrc(base, bytes), (vt_ldsptr)dst, 16, 16u * lane, 0, 0, 0);
+        }
+    };
+    auto load_d = [&](int t, double (&dv)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            int64_t row = r0 + (int64_t)t * kKC + 4 * s + q;
+            dv[s] = a.d[row < a.N ? row : a.N - 1];   // rows past the chunk meet zero-filled X
+        }
+    };
+
+    f64x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+    double dcur[4], dnxt[4];
+    load_d(0, dcur);
+    issue(0, 0);
+    issue(1, 1);
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+        lg_wait4_barrier();
+        load_d(t + 1, dnxt);                       // before the DMA issue: the newest 4 stay the DMAs
+        __builtin_amdgcn_sched_barrier(0);
+        const int b2 = buf == 0 ? 2 : buf - 1;
+        issue(t + 2, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!skip) {
+            const double* pa = lds + buf * (2 * PANEL) + q * RSTR + 64 * wm + c;
+            const double* pb = lds + buf * (2 * PANEL) + PANEL + q * RSTR + 32 * wn + c;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                double af[4], bf[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = pa[4 * s * RSTR + 16 * i];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = dcur[s] * pb[4 * s * RSTR + 16 * j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dcur[s] = dnxt[s];
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[(wm * 64 + 16 * i + q + 4 * r) * kT + wn * 32 + 16 * j + c] = acc[i][j][r];
 }
 
 // H[i][j] = H[j][i] = sum_chunks part (+ prior on the diagonal), i >= j.
@@ -356,12 +570,23 @@ int vt_large_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, co
     return vt_launch_status();
 }
 
+// Split of the N axis: one 512-thread workgroup per CU at a time, so pick the split whose grid
+// (ntl * ks workgroups) fills whole rounds of the chip best.
 static int syrk_split(int ntl) {
-    int want = 2 * num_cu();
-    int ks = (want + ntl - 1) / ntl;
-    if (ks < 1) ks = 1;
-    if (ks > 64) ks = 64;
-    return ks;
+    const int cu = num_cu();
+    int best = 1;
+    double best_eff = 0.0;
+    for (int ks = 1; ks <= 64; ++ks) {
+        const int64_t wgs = (int64_t)ntl * ks;
+        const int64_t rounds = (wgs + cu - 1) / cu;
+        double eff = (double)wgs / (double)(rounds * cu);
+        if (rounds < 2) eff *= 0.9;          // a single round has no tail to hide the ramp
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best = ks;
+        }
+    }
+    return best;
 }
 
 size_t vt_large_syrk_ws_bytes(int D) {
@@ -376,7 +601,19 @@ int vt_large_syrk(const double* X, int64_t ldx, const double* d, int64_t N, int 
     int64_t nsteps = (N + 3) / 4;
     if (ks > nsteps) ks = (int)std::max<int64_t>(1, nsteps);
     SyrkArgs a{X, ldx, d, N, D, nt, ks, (double*)ws};
-    hipLaunchKernelGGL(k_syrk_tile, dim3(ntl, ks), dim3(256), 0, st, a);
+    if (ldx % 2 == 0 && (uintptr_t)X % 16 == 0 && !getenv("VT_LARGE_NO_LDS")) {
+        const size_t shmem = (size_t)kStages * 2 * kKC * (kT + 16) * sizeof(double);   // 108 KB
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)k_syrk_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) !=
+                hipSuccess)
+                return VT_ERR_HIP;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_syrk_lds, dim3(ntl, ks), dim3(512), shmem, st, a);
+    } else {
+        hipLaunchKernelGGL(k_syrk_tile, dim3(ntl, ks), dim3(256), 0, st, a);
+    }
     hipLaunchKernelGGL(k_syrk_reduce, dim3(ntl), dim3(1024), 0, st, (const double*)ws, nt, ks, D, prior, H, ldh);
     return vt_launch_status();
 }
