@@ -8,8 +8,9 @@
 //                 (32-byte loads) -- A and B use the same permutation, so the product is unchanged.
 //   blocked Cholesky (128-wide panels): diagonal block by k_potrf_pack_small, panel by the MFMA
 //                 TRSM in forward-only mode, trailing update by k_gemm_nt.
-//   blocked TRSM  S = alpha s .* B (L L^T)^{-1}: per 128-column block one k_gemm_nt update and one
-//                 small-TRSM solve with the block's inverted-diagonal pack.
+//   blocked TRSM  S = alpha s .* B (L L^T)^{-1}: per 128-column block one GEMM-NT update (whose epilogue
+//                 also applies the row scale: alpha s .* B is never materialised) and one small-TRSM
+//                 solve with the block's inverted-diagonal pack.
 // Replaces the same reference lines as the small-D kernels (see include/vittles_hip.h).
 #include "vt_common.h"
 #include <cstdlib>
@@ -42,6 +43,11 @@ struct GemmArgs {
     int64_t ldb;
     int K;
     double alpha, beta;
+    // optional: take the beta term from another matrix, row-scaled:  C = alpha A B^T + cscale * rowscale[m] * Csrc[m][n]
+    const double* Csrc;
+    int64_t ldcs;
+    const double* rowscale;
+    double cscale;
 };
 
 // 4 consecutive k of one row: vector loads when the group is inside [0, K), zero otherwise.
@@ -113,7 +119,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a) {
                 if (m < a.M && n < a.N) {
                     double* p = a.C + m * a.ldc + n;
                     double v = a.alpha * acc[i][j][r];
-                    if (a.beta != 0.0) v = fma(a.beta, *p, v);
+                    if (a.Csrc) v = fma(a.cscale * (a.rowscale ? a.rowscale[m] : 1.0), a.Csrc[m * a.ldcs + n], v);
+                    else if (a.beta != 0.0) v = fma(a.beta, *p, v);
                     *p = v;
                 }
             }
@@ -213,7 +220,8 @@ __global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
                 if (m < a.M && n < a.N) {
                     double* p = a.C + m * a.ldc + n;
                     double v = a.alpha * acc[i][j][r];
-                    if (a.beta != 0.0) v = fma(a.beta, *p, v);
+                    if (a.Csrc) v = fma(a.cscale * (a.rowscale ? a.rowscale[m] : 1.0), a.Csrc[m * a.ldcs + n], v);
+                    else if (a.beta != 0.0) v = fma(a.beta, *p, v);
                     *p = v;
                 }
             }
@@ -226,9 +234,10 @@ bool lds_path_ok(const double* A, int64_t lda, const double* B, int64_t ldb, int
 }
 
 int gemm_nt(double* C, int64_t ldc, int64_t M, int N, const double* A, int64_t lda, const double* B,
-            int64_t ldb, int K, double alpha, double beta, bool lower, hipStream_t st) {
+            int64_t ldb, int K, double alpha, double beta, bool lower, hipStream_t st,
+            const double* Csrc = nullptr, int64_t ldcs = 0, const double* rowscale = nullptr, double cscale = 1.0) {
     if (M <= 0 || N <= 0) return VT_OK;
-    GemmArgs a{C, ldc, M, N, A, lda, B, ldb, K, alpha, beta};
+    GemmArgs a{C, ldc, M, N, A, lda, B, ldb, K, alpha, beta, Csrc, ldcs, rowscale, cscale};
     dim3 grid((unsigned)((M + kT - 1) / kT), (unsigned)((N + kT - 1) / kT));
     if (lds_path_ok(A, lda, B, ldb, K)) {
         const size_t shmem = (size_t)kStages * 2 * (kKC / 2) * kT * 2 * sizeof(double);   // 96 KB
@@ -457,19 +466,6 @@ __global__ void k_syrk_reduce(const double* part, int nt, int ksplit, int D, con
 }
 
 // ------------------------------------------------------------------ small helpers -------
-// Out[n][c] = alpha * s_n * B[n][c]
-__global__ void k_scale_rows(const double* B, int64_t ldb, const double* s, double alpha, int64_t N, int D,
-                             double* Out, int64_t ldo) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = N * D;
-    for (; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        int64_t n = idx / D;
-        int cidx = (int)(idx - n * D);
-        double f = s ? alpha * s[n] : alpha;
-        Out[n * ldo + cidx] = f * B[n * ldb + cidx];
-    }
-}
-
 // Lc = tril(L) (ld D), LT = Lc^T
 __global__ void k_copy_lower_and_transpose(const double* L, int ldl, int D, double* Lc, double* LT) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -540,20 +536,19 @@ int vt_large_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, co
     const double* LT = Lc + (size_t)D * D;
     const double* packs = LT + (size_t)D * D;
     const int nblk = (D + kT - 1) / kT;
-    {
-        int64_t tot = N * D;
-        int64_t g = (tot + 255) / 256;
-        if (g > 65535) g = 65535;
-        hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)g), dim3(256), 0, st, B, ldb, rowscale, alpha, N, D, Out, ldo);
-    }
+    // forward:  Y L^T = G with G = alpha * s .* B never materialised: block 0 takes it through the
+    // small solve's row scale, the later blocks through the update's epilogue.
     int rc;
-    for (int J = 0; J < nblk; ++J) {   // forward:  Y L^T = G
+    for (int J = 0; J < nblk; ++J) {
         const int o = J * kT, Db = std::min(kT, D - o);
-        if (J > 0) {
-            rc = gemm_nt(Out + o, ldo, N, Db, Out, ldo, Lc + (int64_t)o * D, D, o, -1.0, 1.0, false, st);
+        if (J == 0) {
+            rc = vt_trsm_rows_mode(packs, Db, B, ldb, rowscale, alpha, N, Out, ldo, 1, st);
+        } else {
+            rc = gemm_nt(Out + o, ldo, N, Db, Out, ldo, Lc + (int64_t)o * D, D, o, -1.0, 0.0, false, st, B + o, ldb,
+                         rowscale, alpha);
             if (rc != VT_OK) return rc;
+            rc = vt_trsm_rows_mode(packs + (size_t)J * kPackStride, Db, Out + o, ldo, nullptr, 1.0, N, Out + o, ldo, 1, st);
         }
-        rc = vt_trsm_rows_mode(packs + (size_t)J * kPackStride, Db, Out + o, ldo, nullptr, 1.0, N, Out + o, ldo, 1, st);
         if (rc != VT_OK) return rc;
     }
     for (int J = nblk - 1; J >= 0; --J) {   // backward:  Z L = Y
