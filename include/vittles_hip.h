@@ -55,8 +55,12 @@ extern "C" {
 #define VT_FAMILY_GAUSSIAN 2
 
 /* Largest D handled by the register/LDS-resident ("small-D") SYRK / Cholesky /
- * TRSM kernels.  Larger D takes the tiled kernels. */
+ * TRSM kernels.  Larger D (up to VT_DENSE_D_MAX) takes the tiled kernels; the
+ * row-streaming entry points (link, grad, HVP, gemv, value) take D <= VT_ROWS_D_MAX.
+ * Anything larger returns VT_ERR_UNSUPPORTED. */
 #define VT_SMALL_D_MAX 128
+#define VT_DENSE_D_MAX 8192
+#define VT_ROWS_D_MAX  20448
 
 int         vt_version(void);
 const char* vt_error_string(int code);
