@@ -187,7 +187,7 @@ def main():
                      "TFLOPs_full_square": 2.0 * N * D * D / (ms_hess * 1e-3) / 1e12,
                      "hbm_GBs": (8.0 * N * D + 24.0 * N) / (ms_hess * 1e-3) / 1e9},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 at N=1 only
             n_s = min(args.cpu_rows, N)
             Xh = X[:n_s].cpu().numpy()
             yh = y[:n_s].cpu().numpy()

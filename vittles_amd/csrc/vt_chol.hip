@@ -3,6 +3,9 @@
 // (vittles/solver_lib.py:26-29) and the N-right-hand-side solve behind
 // `-1 * self._hess_solver(jac0)` (vittles/sensitivity_lib.py:226).
 #include "vt_common.h"
+#ifndef VT_PABL
+#define VT_PABL 0   // dev-only compile-time ablation mask
+#endif
 
 namespace {
 
@@ -37,70 +40,104 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(double* A, int lda, in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NB = (D + 15) >> 4, NP = NB * 16, NBT = NB * (NB + 1) / 2;
     if (tid == 0) s_bad = 0;
-    for (int idx = tid; idx < NP * NP; idx += 256) {
-        int i = idx / NP, j = idx - i * NP;
-        double v = 0.0;
-        if (i < D && j <= i) v = A[(int64_t)i * lda + j];
-        if (i >= D && j == i) v = 1.0;
-        a[i * kSmallLd + j] = v;
+    // zero-padded lower triangle -> LDS (identity on the padding diagonal); 128 threads per row
+    for (int i = tid >> 7; i < NP; i += 2) {
+        const int j = tid & 127;
+        if (j < NP) {
+            double v = 0.0;
+            if (i < D && j <= i) v = A[(int64_t)i * lda + j];
+            if (i >= D && j == i) v = 1.0;
+            a[i * kSmallLd + j] = v;
+        }
     }
     __syncthreads();
-    for (int J = 0; J < NB; ++J) {
+
+    // (a) diagonal block J: factor (optional) + invert in registers, lane r = row r.  Wave 0 only.
+    auto diag_block = [&](int J) {
         const int o = 16 * J;
-        if (wave == 0) {
-            // ---- (a) diagonal block: factor + invert in registers, lane r = row r ----------
-            const int r = lane & 15;
-            double row[16];
+        const int r = lane & 15;
+        double row[16];
 #pragma unroll
-            for (int cc = 0; cc < 16; ++cc) row[cc] = a[(o + r) * kSmallLd + o + cc];
-            int bad = 0;
-            double rdiag[16];
-            if (do_factor) {
+        for (int cc = 0; cc < 16; ++cc) row[cc] = a[(o + r) * kSmallLd + o + cc];
+        int bad = 0;
+        double rdiag[16];
+        if (do_factor) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    double akk = readlane_f64(row[k], k);
-                    if (!(akk > 0.0) && bad == 0 && o + k < D) bad = o + k + 1;
-                    double piv = sqrt(akk > 0.0 ? akk : 1.0);
-                    double rp = 1.0 / piv;
-                    rdiag[k] = rp;
-                    double lk = r > k ? row[k] * rp : 0.0;
-                    row[k] = r == k ? piv : lk;
+            for (int k = 0; k < 16; ++k) {
+                double akk = readlane_f64(row[k], k);
+                if (!(akk > 0.0) && bad == 0 && o + k < D) bad = o + k + 1;
+                // 1/sqrt by v_rsq_f64 + two Newton steps (the IEEE sqrt and divide sequences are
+                // ~80 dependent instructions per column of this 16-long serial chain)
+                const double ap = akk > 0.0 ? akk : 1.0;
+                double rp = __builtin_amdgcn_rsq(ap);
+                rp = rp * fma(-0.5 * ap * rp, rp, 1.5);
+                rp = rp * fma(-0.5 * ap * rp, rp, 1.5);
+                double piv = ap * rp;
+                piv = fma(fma(-piv, piv, ap), 0.5 * rp, piv);   // one correction step of sqrt itself
+                rdiag[k] = rp;
+                double lk = r > k ? row[k] * rp : 0.0;
+                row[k] = r == k ? piv : lk;
 #pragma unroll
-                    for (int j = k + 1; j < 16; ++j) {
-                        double ljk = readlane_f64(lk, j);
-                        row[j] = fma(-lk, ljk, row[j]);
-                    }
+                for (int j = k + 1; j < 16; ++j) {
+                    double ljk = readlane_f64(lk, j);
+                    row[j] = fma(-lk, ljk, row[j]);
                 }
-                if (lane < 16) {
-#pragma unroll
-                    for (int cc = 0; cc < 16; ++cc) a[(o + r) * kSmallLd + o + cc] = cc <= r ? row[cc] : 0.0;
-                }
-                if (bad && lane == 0) s_bad = bad;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) rdiag[k] = 1.0 / readlane_f64(row[k], k);
-            }
-            // inverse: lane c holds column c of L_JJ^{-1}:  x_i = (delta_ic - sum_{m<i} L[i][m] x_m) / L[i][i]
-            const int c = r;
-            double x[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double sacc = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-                for (int m = 0; m < i; ++m) sacc = fma(-readlane_f64(row[m], i), x[m], sacc);
-                x[i] = i < c ? 0.0 : sacc * rdiag[i];
             }
             if (lane < 16) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) linv[(J * 16 + i) * 17 + c] = x[i];
+                for (int cc = 0; cc < 16; ++cc) a[(o + r) * kSmallLd + o + cc] = cc <= r ? row[cc] : 0.0;
             }
+            if (bad && lane == 0) s_bad = bad;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) rdiag[k] = vt_rcp(readlane_f64(row[k], k));
         }
+        // inverse: lane c holds column c of L_JJ^{-1}:  x_i = (delta_ic - sum_{m<i} L[i][m] x_m) / L[i][i]
+        const int c = r;
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double sacc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int m = 0; m < i; ++m) sacc = fma(-readlane_f64(row[m], i), x[m], sacc);
+            x[i] = i < c ? 0.0 : sacc * rdiag[i];
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) linv[(J * 16 + i) * 17 + c] = x[i];
+        }
+    };
+    // (c) one trailing tile  A_ik -= L_iJ L_kJ^T  on the MFMA, straight from LDS
+    auto trailing_tile = [&](int o, int bi, int bk) {
+        const int q = lane >> 4, cl = lane & 15;
+        const int ri = o + 16 + 16 * bi, rk = o + 16 + 16 * bk;
+        f64x4 cacc;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) cacc[rr] = a[(ri + q + 4 * rr) * kSmallLd + rk + cl];
+        double av[4], bv[4];
+#pragma unroll
+        for (int sstep = 0; sstep < 4; ++sstep) {
+            av[sstep] = -a[(ri + cl) * kSmallLd + o + 4 * sstep + q];
+            bv[sstep] = a[(rk + cl) * kSmallLd + o + 4 * sstep + q];
+        }
+#pragma unroll
+        for (int sstep = 0; sstep < 4; ++sstep) cacc = mfma_f64(av[sstep], bv[sstep], cacc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) a[(ri + q + 4 * rr) * kSmallLd + rk + cl] = cacc[rr];
+    };
+
+    if (!do_factor) {
+        // A already holds L: only the inverted diagonal blocks are needed (one per wave at a time)
+        for (int J = wave; J < NB; J += 4) diag_block(J);
+    } else {
+        if (wave == 0 && !(VT_PABL & 1)) diag_block(0);
         __syncthreads();
-        if (s_bad) break;
-        if (do_factor && J + 1 < NB) {
+        for (int J = 0; J < NB && !s_bad; ++J) {
+            const int o = 16 * J;
+            if (J + 1 == NB) break;
             // ---- (b) panel: row R of the blocks below:  L[R][o..o+15] = A[R][o..] * Linv^T ----
             const int R = o + 16 + tid;
-            if (R < NP) {
+            if (R < NP && !(VT_PABL & 2)) {
                 double t[16], u[16];
 #pragma unroll
                 for (int m = 0; m < 16; ++m) t[m] = a[R * kSmallLd + o + m];
@@ -115,26 +152,19 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(double* A, int lda, in
                 for (int cc = 0; cc < 16; ++cc) a[R * kSmallLd + o + cc] = u[cc];
             }
             __syncthreads();
-            // ---- (c) trailing update  A_ik -= L_iJ L_kJ^T,  J < k <= i, on the MFMA --------
+            // ---- (c) trailing update with look-ahead: wave 0 updates the next diagonal block first and
+            //      factors it while waves 1..3 update the rest of the trailing matrix --------------------
             const int nb = NB - J - 1;
             const int nt = nb * (nb + 1) / 2;
-            const int q = lane >> 4, cl = lane & 15;
-            for (int t = wave; t < nt; t += 4) {
-                int bi = 0;
-                while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-                int bk = t - bi * (bi + 1) / 2;
-                const int ri = o + 16 + 16 * bi, rk = o + 16 + 16 * bk;
-                f64x4 cacc;
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) cacc[rr] = a[(ri + q + 4 * rr) * kSmallLd + rk + cl];
-#pragma unroll
-                for (int sstep = 0; sstep < 4; ++sstep) {
-                    double av = -a[(ri + cl) * kSmallLd + o + 4 * sstep + q];
-                    double bv = a[(rk + cl) * kSmallLd + o + 4 * sstep + q];
-                    cacc = mfma_f64(av, bv, cacc);
+            if (wave == 0) {
+                if (!(VT_PABL & 4)) trailing_tile(o, 0, 0);
+                if (!(VT_PABL & 1)) diag_block(J + 1);
+            } else if (!(VT_PABL & 4)) {
+                for (int t = wave; t < nt; t += 3) {    // tiles 1..nt-1 over waves 1..3
+                    int bi = 0;
+                    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+                    trailing_tile(o, bi, t - bi * (bi + 1) / 2);
                 }
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) a[(ri + q + 4 * rr) * kSmallLd + rk + cl] = cacc[rr];
             }
             __syncthreads();
         }
@@ -142,13 +172,13 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(double* A, int lda, in
     __syncthreads();
     const int bad = s_bad;
     if (do_factor) {
-        for (int idx = tid; idx < D * D; idx += 256) {
-            int i = idx / D, j = idx - i * D;
+        for (int i = tid >> 7; i < D; i += 2) {
+            const int j = tid & 127;
             if (j <= i) A[(int64_t)i * lda + j] = a[i * kSmallLd + j];
         }
         if (tid == 0 && info) *info = bad;
     }
-    if (pack == nullptr || bad) return;
+    if (pack == nullptr || bad || (VT_PABL & 8)) return;
     // ---- TRSM operand pack (see vt_trsm_pack) ---------------------------------------------
     const bool lastperm = (D & 15) == 0;
     const int total = 2 * NBT * 256;
