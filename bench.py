@@ -36,6 +36,9 @@ def parse():
     p.add_argument("--dim", type=int, default=100)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-rows", type=int, default=1_000_000)
+    p.add_argument("--no-hvp", action="store_true", help="skip the HVP GB/s side measurement")
+    p.add_argument("--hvp-rows", type=int, default=100_000)
+    p.add_argument("--hvp-dim", type=int, default=20_000)
     return p.parse_args()
 
 
@@ -62,6 +65,32 @@ def cpu_baseline(Xh, yh, wh, theta_h, prior, S_dev_rows, n_sample):
                        "%d rows of the same N x D workload, %.2f s" % (n, dt)), H, S
 
 
+def hvp_side_measurement(torch, device, n_rows, dim, reps=10):
+    """The metric's second figure: fused HVP kernel (BASELINE.json configs[3], D = 20k
+    ridge-logistic CG) in algorithmic GB/s = (8ND + 8N + 16D) / kernel time, HIP events on
+    the launch stream.  Runs after the timed region of the headline step, rank 0 only."""
+    from vittles_amd import rows
+    X = torch.randn((n_rows, dim), dtype=torch.float64, device=device)
+    d = torch.rand(n_rows, dtype=torch.float64, device=device)
+    v = torch.randn(dim, dtype=torch.float64, device=device)
+    out = torch.empty(dim, dtype=torch.float64, device=device)
+    for _ in range(3):
+        rows.glm_hvp(X, d, v, prior_scalar=1.0, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        rows.glm_hvp(X, d, v, prior_scalar=1.0, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = 8.0 * n_rows * dim + 8.0 * n_rows + 16.0 * dim
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    del X
+    return {"kernel": "k_rows_wide<OP_HVP> (K6 fused HVP)", "rows": n_rows, "dim": dim, "ms": ms,
+            "algorithmic_bytes": nbytes, "GBs": gbs, "peak_GBs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}
+
+
 def main():
     args = parse()
     import torch
@@ -72,12 +101,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; VITTLES_BENCH_BACKEND=gloo lets several ranks share one card to
+    # rehearse the multi-rank code path on a one-GPU box (RCCL refuses duplicate devices)
+    backend = os.environ.get("VITTLES_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
 
     import vittles_amd as va
@@ -187,6 +223,8 @@ def main():
                      "TFLOPs_full_square": 2.0 * N * D * D / (ms_hess * 1e-3) / 1e12,
                      "hbm_GBs": (8.0 * N * D + 24.0 * N) / (ms_hess * 1e-3) / 1e9},
         }
+        if not args.no_hvp:
+            result["hvp"] = hvp_side_measurement(torch, device, args.hvp_rows, args.hvp_dim)
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 at N=1 only
             n_s = min(args.cpu_rows, N)
             Xh = X[:n_s].cpu().numpy()

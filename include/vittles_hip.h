@@ -157,6 +157,20 @@ int    vt_glm_hvp(const double* X_dev, int64_t ldx, const double* d_dev, const d
 int    vt_gemv_t(const double* A_dev, int64_t lda, const double* u_dev, int64_t N, int D,
                  double* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* K9, many weight vectors at once:  C (Da, Db) = alpha * A^T diag(s) B + 1 bias^T  for row-major
+ * A (N, Da), B (N, Db); s (N,) and bias (Db,) may be NULL.  fp64 MFMA, N axis split over the chip,
+ * fixed-order reduction.  With A = the matrix whose COLUMNS are new weight vectors (bootstrap draws,
+ * K-fold / leave-one-out indicator weights), B = S and bias = theta-hat - S^T w0 this is
+ * Replaces: `self._sens_mat @ (new_hyper_par_value - self._hyper_val0)`
+ *             vittles/sensitivity_lib.py:245-247 called once per weight vector in a Python loop
+ *             (docs/source/example_notebooks/mle_weight_sensitivity_example.ipynb cells 24-26;
+ *              bootstrap weights: docs/source/example_notebooks/example_utils.py:19-20).
+ * Da, Db <= VT_DENSE_D_MAX; workspace from vt_gemm_tn_workspace_bytes (0 = unsupported shape). */
+size_t vt_gemm_tn_workspace_bytes(int Da, int Db);
+int    vt_gemm_tn(const double* A_dev, int64_t lda, int Da, const double* B_dev, int64_t ldb, int Db,
+                  const double* rowscale_dev, int64_t N, double alpha, const double* bias_dev,
+                  double* C_dev, int64_t ldc, void* ws_dev, size_t ws_bytes, void* stream);
+
 /* out (N,) = A v for a row-major (N, D) A (moment Jacobians times a vector, K8). */
 int    vt_gemv(const double* A_dev, int64_t lda, const double* v_dev, int64_t N, int D,
                double* out_dev, void* ws_dev, size_t ws_bytes, void* stream);

@@ -272,20 +272,39 @@ struct SyrkArgs {
     int nt;        // tiles per side
     int ksplit;
     double* part;  // [ksplit][ntl][128*128]
+    // GEN (two-operand) mode:  C = X^T diag(d) B  with B (N x Db); nt x ntb rectangular tile grid
+    const double* B;
+    int64_t ldb;
+    int Db;
+    int ntb;
 };
 
+// tile index -> (ti, tj): lower triangle (SYRK) or ti * ntb + tj (two-operand product)
+template <bool GEN>
+__device__ __forceinline__ void tile_of(const SyrkArgs& a, int t, int& ti, int& tj) {
+    if constexpr (GEN) {
+        ti = t / a.ntb;
+        tj = t - ti * a.ntb;
+    } else {
+        ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        tj = t - ti * (ti + 1) / 2;
+    }
+}
+
+template <bool GEN>
 __global__ __launch_bounds__(256) void k_syrk_tile(SyrkArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
-    // lower-triangular tile index -> (ti, tj), tj <= ti
-    int t = blockIdx.x, ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tj = t - ti * (ti + 1) / 2;
+    int t = blockIdx.x, ti, tj;
+    tile_of<GEN>(a, t, ti, tj);
     const int wm = wave >> 1, wn = wave & 1;
     const int i0 = ti * kT + wm * 64, j0 = tj * kT + wn * 64;
-    const int ntl = a.nt * (a.nt + 1) / 2;
+    const int ntl = GEN ? a.nt * a.ntb : a.nt * (a.nt + 1) / 2;
+    const int Dj = GEN ? a.Db : a.D;
     double* out = a.part + ((int64_t)blockIdx.y * ntl + t) * (kT * kT);
-    const bool skip = (ti == tj && wn > wm) || i0 >= a.D || j0 >= a.D;   // wave strictly above the diagonal
+    // wave strictly above the diagonal (SYRK) or entirely in the padding
+    const bool skip = (!GEN && ti == tj && wn > wm) || i0 >= a.D || j0 >= Dj;
 
     const int64_t nsteps = (a.N + 3) >> 2;
     const int64_t per = (nsteps + a.ksplit - 1) / a.ksplit;
@@ -303,7 +322,7 @@ __global__ __launch_bounds__(256) void k_syrk_tile(SyrkArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             ca[i] = min(i0 + 16 * i + c, a.D - 1);
-            cb[i] = min(j0 + 16 * i + c, a.D - 1);
+            cb[i] = min(j0 + 16 * i + c, Dj - 1);
         }
         struct Buf { double xa[4], xb[4], dn; };
         auto load = [&](int64_t s, Buf& b) {
@@ -311,12 +330,13 @@ __global__ __launch_bounds__(256) void k_syrk_tile(SyrkArgs a) {
             bool ok = s < s1 && n < a.N;
             int64_t nc = n < a.N ? n : a.N - 1;
             const double* xr = a.X + nc * a.ldx;
+            const double* br = GEN ? a.B + nc * a.ldb : xr;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 b.xa[i] = xr[ca[i]];
-                b.xb[i] = xr[cb[i]];
+                b.xb[i] = br[cb[i]];
             }
-            double dv = a.d[nc];
+            double dv = a.d ? a.d[nc] : 1.0;
             b.dn = ok ? dv : 0.0;
         };
         auto compute = [&](const Buf& b) {
@@ -356,6 +376,7 @@ __global__ __launch_bounds__(256) void k_syrk_tile(SyrkArgs a) {
 
 // LDS-staged version: panels [n][col] (row stride 144 doubles = 16 mod 32: conflict-free operand
 // reads), one DMA instruction per row of a panel, d_n fetched a stage ahead.
+template <bool GEN>
 __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
     extern __shared__ double lds[];            // [kStages][I: 16 x 144 | J: 16 x 144]
     constexpr int RSTR = kT + 16, PANEL = kKC * RSTR;
@@ -363,19 +384,19 @@ __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int q = lane >> 4, c = lane & 15;
-    int t_id = blockIdx.x, ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= t_id) ++ti;
-    const int tj = t_id - ti * (ti + 1) / 2;
-    const int ntl = a.nt * (a.nt + 1) / 2;
+    int t_id = blockIdx.x, ti, tj;
+    tile_of<GEN>(a, t_id, ti, tj);
+    const int ntl = GEN ? a.nt * a.ntb : a.nt * (a.nt + 1) / 2;
     double* out = a.part + ((int64_t)blockIdx.y * ntl + t_id) * (kT * kT);
-    const bool skip = ti == tj && 32 * wn >= 64 * (wm + 1);   // sub-tile strictly above the diagonal
 
     int64_t per = (a.N + a.ksplit - 1) / a.ksplit;
     per = (per + kKC - 1) / kKC * kKC;
     const int64_t r0 = (int64_t)blockIdx.y * per;
     const int64_t r1 = min(a.N, r0 + per);
     const int nk = r1 > r0 ? (int)((r1 - r0 + kKC - 1) / kKC) : 0;
-    const int icols = min(kT, a.D - ti * kT), jcols = min(kT, a.D - tj * kT);
+    const int icols = min(kT, a.D - ti * kT), jcols = min(kT, (GEN ? a.Db : a.D) - tj * kT);
+    // sub-tile strictly above the diagonal (SYRK), or entirely in the zero padding of the tile
+    const bool skip = (!GEN && ti == tj && 32 * wn >= 64 * (wm + 1)) || 64 * wm >= icols || 32 * wn >= jcols;
 
     auto issue = [&](int t, int buf) {
 #pragma unroll
@@ -385,7 +406,8 @@ __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
             const int n = id & 15;
             const int64_t row = r0 + (int64_t)t * kKC + n;
             const bool ok = t < nk && row < r1;
-            const double* base = a.X + (ok ? row : 0) * a.ldx + (isj ? tj : ti) * kT;
+            const double* base = (GEN && isj) ? a.B + (ok ? row : 0) * a.ldb + tj * kT
+                                              : a.X + (ok ? row : 0) * a.ldx + (isj ? tj : ti) * kT;
             const unsigned bytes = ok ? 8u * (isj ? jcols : icols) : 0u;
             double* dst = lds + buf * (2 * PANEL) + (isj ? PANEL : 0) + n * RSTR;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(lg_rsrc(base, bytes), (vt_ldsptr)dst, 16, 16u * lane, 0, 0, 0);
@@ -395,7 +417,7 @@ __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             int64_t row = r0 + (int64_t)t * kKC + 4 * s + q;
-            dv[s] = a.d[row < a.N ? row : a.N - 1];   // rows past the chunk meet zero-filled X
+            dv[s] = (GEN && !a.d) ? 1.0 : a.d[row < a.N ? row : a.N - 1];   // rows past the chunk meet zero-filled X
         }
     };
 
@@ -462,6 +484,21 @@ __global__ void k_syrk_reduce(const double* part, int nt, int ksplit, int D, con
         if (i == j && prior) s += prior[i];
         H[(int64_t)i * ldh + j] = s;
         H[(int64_t)j * ldh + i] = s;
+    }
+}
+
+// C[i][j] = alpha * sum_chunks part + bias[j]   (i < Da, j < Db): the two-operand product's epilogue.
+__global__ void k_gemm_tn_reduce(const double* part, int ntb, int ntl, int ksplit, int Da, int Db, double alpha,
+                                 const double* bias, double* C, int64_t ldc) {
+    const int t = blockIdx.x, ti = t / ntb, tj = t - ti * ntb;
+    for (int e = threadIdx.x; e < kT * kT; e += blockDim.x) {
+        int i = ti * kT + e / kT, j = tj * kT + e % kT;
+        if (i >= Da || j >= Db) continue;
+        double s = 0.0;
+        for (int k = 0; k < ksplit; ++k) s += part[((int64_t)k * ntl + t) * (kT * kT) + e];
+        s *= alpha;
+        if (bias) s += bias[j];
+        C[(int64_t)i * ldc + j] = s;
     }
 }
 
@@ -567,11 +604,11 @@ int vt_large_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, co
 
 // Split of the N axis: one 512-thread workgroup per CU at a time, so pick the split whose grid
 // (ntl * ks workgroups) fills whole rounds of the chip best.
-static int syrk_split(int ntl) {
+static int syrk_split(int ntl, int ks_max = 64) {
     const int cu = num_cu();
     int best = 1;
     double best_eff = 0.0;
-    for (int ks = 1; ks <= 64; ++ks) {
+    for (int ks = 1; ks <= ks_max; ++ks) {
         const int64_t wgs = (int64_t)ntl * ks;
         const int64_t rounds = (wgs + cu - 1) / cu;
         double eff = (double)wgs / (double)(rounds * cu);
@@ -595,20 +632,65 @@ int vt_large_syrk(const double* X, int64_t ldx, const double* d, int64_t N, int 
     int ks = syrk_split(ntl);
     int64_t nsteps = (N + 3) / 4;
     if (ks > nsteps) ks = (int)std::max<int64_t>(1, nsteps);
-    SyrkArgs a{X, ldx, d, N, D, nt, ks, (double*)ws};
+    SyrkArgs a{X, ldx, d, N, D, nt, ks, (double*)ws, nullptr, 0, 0, 0};
     if (ldx % 2 == 0 && (uintptr_t)X % 16 == 0 && !getenv("VT_LARGE_NO_LDS")) {
         const size_t shmem = (size_t)kStages * 2 * kKC * (kT + 16) * sizeof(double);   // 108 KB
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)k_syrk_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) !=
-                hipSuccess)
+            if (hipFuncSetAttribute((const void*)k_syrk_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)shmem) != hipSuccess)
                 return VT_ERR_HIP;
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_syrk_lds, dim3(ntl, ks), dim3(512), shmem, st, a);
+        hipLaunchKernelGGL(k_syrk_lds<false>, dim3(ntl, ks), dim3(512), shmem, st, a);
     } else {
-        hipLaunchKernelGGL(k_syrk_tile, dim3(ntl, ks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_syrk_tile<false>, dim3(ntl, ks), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(k_syrk_reduce, dim3(ntl), dim3(1024), 0, st, (const double*)ws, nt, ks, D, prior, H, ldh);
+    return vt_launch_status();
+}
+
+// ------------------------------------------------------------------ two-operand product -------
+// C (Da x Db) = alpha * A^T diag(s) B + 1 bias^T for row-major A (N x Da), B (N x Db): the SYRK
+// kernels with a second operand and a rectangular tile grid; the N axis is split so that the
+// grid fills the chip even when there is a single output tile.
+static int gemm_tn_split(int ntl) {
+    const int cu = num_cu();
+    return syrk_split(ntl, std::max(1, std::min(512, 2 * cu / ntl)));
+}
+
+extern "C" size_t vt_gemm_tn_workspace_bytes(int Da, int Db) {
+    if (Da < 1 || Db < 1 || Da > VT_DENSE_D_MAX || Db > VT_DENSE_D_MAX) return 0;
+    const int nta = (Da + kT - 1) / kT, ntb = (Db + kT - 1) / kT;
+    return (size_t)gemm_tn_split(nta * ntb) * nta * ntb * kT * kT * sizeof(double);
+}
+
+extern "C" int vt_gemm_tn(const double* A, int64_t lda, int Da, const double* B, int64_t ldb, int Db,
+                          const double* rowscale, int64_t N, double alpha, const double* bias, double* C,
+                          int64_t ldc, void* ws, size_t ws_bytes, void* stream) {
+    if (!A || !B || !C || N < 0 || Da < 1 || Db < 1 || lda < Da || ldb < Db || ldc < Db) return VT_ERR_BAD_ARG;
+    if (Da > VT_DENSE_D_MAX || Db > VT_DENSE_D_MAX) return VT_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < vt_gemm_tn_workspace_bytes(Da, Db)) return VT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nta = (Da + kT - 1) / kT, ntb = (Db + kT - 1) / kT, ntl = nta * ntb;
+    int ks = gemm_tn_split(ntl);
+    const int64_t nsteps = (N + kKC - 1) / kKC;
+    if (ks > nsteps) ks = (int)std::max<int64_t>(1, nsteps);
+    SyrkArgs a{A, lda, rowscale, N, Da, nta, ks, (double*)ws, B, ldb, Db, ntb};
+    if (lda % 2 == 0 && ldb % 2 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0 && !getenv("VT_LARGE_NO_LDS")) {
+        const size_t shmem = (size_t)kStages * 2 * kKC * (kT + 16) * sizeof(double);   // 108 KB
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)k_syrk_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)shmem) != hipSuccess)
+                return VT_ERR_HIP;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_syrk_lds<true>, dim3(ntl, ks), dim3(512), shmem, st, a);
+    } else {
+        hipLaunchKernelGGL(k_syrk_tile<true>, dim3(ntl, ks), dim3(256), 0, st, a);
+    }
+    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3(ntl), dim3(1024), 0, st, (const double*)ws, ntb, ntl, ks, Da, Db, alpha,
+                       bias, C, ldc);
     return vt_launch_status();
 }

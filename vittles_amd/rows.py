@@ -47,6 +47,35 @@ def gemv(A, v):
     return out
 
 
+_tn_ws_cache = {}
+
+
+def gemm_tn(A, B, rowscale=None, alpha=1.0, bias=None, out=None):
+    """out (Da, Db) = alpha * A^T diag(rowscale) B + bias[None, :] for row-major CUDA tensors
+    A (N, Da), B (N, Db): K9 for many weight vectors at once (fp64 MFMA, split over N)."""
+    lib = dev.require_gpu()
+    A, B = _rowmajor(A), _rowmajor(B)
+    N, Da = A.shape
+    if B.shape[0] != N:
+        raise ValueError("A and B must have the same number of rows")
+    Db = B.shape[1]
+    nbytes = lib.vt_gemm_tn_workspace_bytes(Da, Db)
+    if nbytes == 0:
+        raise _lib.VittlesHipError("vt_gemm_tn does not support a (%d, %d) product" % (Da, Db))
+    key = (A.device.index, nbytes)
+    ws = _tn_ws_cache.get(key)
+    if ws is None:
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=A.device)
+        _tn_ws_cache.clear()          # one live workspace per process is enough
+        _tn_ws_cache[key] = ws
+    if out is None:
+        out = torch.empty((Da, Db), dtype=torch.float64, device=A.device)
+    _lib.check(lib.vt_gemm_tn(A.data_ptr(), A.stride(0), Da, B.data_ptr(), B.stride(0), Db, dev.ptr(rowscale),
+                              N, float(alpha), dev.ptr(bias), out.data_ptr(), out.stride(0), ws.data_ptr(),
+                              ws.numel() * 8, dev.stream_ptr()), "vt_gemm_tn")
+    return out
+
+
 def glm_link(obj, theta, w, want_z=False):
     """K0: per-row (z,) r, d for a WeightedGLMObjective."""
     lib = dev.require_gpu()

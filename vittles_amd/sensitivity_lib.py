@@ -130,6 +130,25 @@ class EstimatingEquationLinearApproximation:
         out = rows.gemv_t(self._sens_rows, delta) + dev.to_device(self._input_val0, devc)
         return dev.like_input(out, self._input_val0)
 
+    def predict_input_par_from_hyper_par_batch(self, new_hyper_par_values):
+        """Build-side extension: the reference's
+        ``predict_input_par_from_hyper_par`` (:236-247) for MANY hyper-parameter vectors at
+        once.  ``new_hyper_par_values`` is (len(hyper), K): column k is one new hyper
+        vector (a bootstrap draw, a K-fold or leave-one-out weight vector -- the notebook
+        loops ``predict_opt_par_from_hyper_par`` over them, cells 24-26).  Returns
+        (len(input), K): column k == ``predict_input_par_from_hyper_par(column k)``.
+        One fp64-MFMA product ``W^T S`` over the device-resident S; ``W - hyper0`` is never
+        formed: out = input0 - S^T hyper0 + S^T W."""
+        from . import rows
+        devc = self._sens_rows.device
+        W = dev.to_device(new_hyper_par_values, devc)
+        if W.ndim != 2 or W.shape[0] != self._sens_rows.shape[0]:
+            raise ValueError('new_hyper_par_values must have shape (len(hyper_par), K).')
+        bias = dev.to_device(self._input_val0, devc) - \
+            rows.gemv_t(self._sens_rows, dev.to_device(self._hyper_val0, devc))
+        out = rows.gemm_tn(W, self._sens_rows, bias=bias)        # (K, D) row-major
+        return dev.like_input(out.t(), self._input_val0)
+
     def get_input_par_function(self):
         raise NotImplementedError(
             'get_input_par_function builds an autograd primitive in the reference '
@@ -201,6 +220,9 @@ class HyperparameterSensitivityLinearApproximation(EstimatingEquationLinearAppro
 
     def predict_opt_par_from_hyper_par(self, new_hyper_par_value):
         return super().predict_input_par_from_hyper_par(new_hyper_par_value)
+
+    def predict_opt_par_from_hyper_par_batch(self, new_hyper_par_values):
+        return super().predict_input_par_from_hyper_par_batch(new_hyper_par_values)
 
     def get_opt_par_function(self):
         return super().get_input_par_function()
