@@ -91,6 +91,12 @@ def hvp_side_measurement(torch, device, n_rows, dim, reps=10):
             "algorithmic_bytes": nbytes, "GBs": gbs, "peak_GBs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}
 
 
+def note(msg):
+    if os.environ.get("VITTLES_BENCH_VERBOSE"):
+        print("[bench rank %s %.1fs] %s" % (os.environ.get("RANK", "0"), time.perf_counter(), msg),
+              file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     import torch
@@ -116,6 +122,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
 
+    note("process group up")
     import vittles_amd as va
     from vittles_amd.linalg import DeviceCholesky
     from vittles_amd import _lib, device as dev
@@ -141,6 +148,7 @@ def main():
         if float(step.norm()) < 1e-12 * max(1.0, float(theta.norm())):
             break
     grad_norm = float(obj.fused(theta.clone(), w)["g"].norm())
+    note("theta-hat found, |g| = %.2e" % grad_norm)
 
     lib = _lib.load()
     S = torch.empty((N, D), dtype=torch.float64, device=device)
@@ -172,12 +180,13 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    note("warm-up done")
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i)
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

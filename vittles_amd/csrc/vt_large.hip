@@ -488,18 +488,29 @@ __global__ void k_syrk_reduce(const double* part, int nt, int ksplit, int D, con
 }
 
 // C[i][j] = alpha * sum_chunks part + bias[j]   (i < Da, j < Db): the two-operand product's epilogue.
-__global__ void k_gemm_tn_reduce(const double* part, int ntb, int ntl, int ksplit, int Da, int Db, double alpha,
-                                 const double* bias, double* C, int64_t ldc) {
-    const int t = blockIdx.x, ti = t / ntb, tj = t - ti * ntb;
-    for (int e = threadIdx.x; e < kT * kT; e += blockDim.x) {
-        int i = ti * kT + e / kT, j = tj * kT + e % kT;
-        if (i >= Da || j >= Db) continue;
-        double s = 0.0;
-        for (int k = 0; k < ksplit; ++k) s += part[((int64_t)k * ntl + t) * (kT * kT) + e];
-        s *= alpha;
-        if (bias) s += bias[j];
-        C[(int64_t)i * ldc + j] = s;
+// One thread per output element (a single tile may be split 512 ways: 64 MB of slabs), slabs summed
+// in a fixed order.
+__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const double* part, int ntb, int ntl, int ksplit, int Da,
+                                                        int Db, double alpha, const double* bias, double* C,
+                                                        int64_t ldc) {
+    const int t = blockIdx.y, ti = t / ntb, tj = t - ti * ntb;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int i = ti * kT + e / kT, j = tj * kT + e % kT;
+    if (i >= Da || j >= Db) return;
+    const double* p = part + (int64_t)t * (kT * kT) + e;
+    const int64_t stride = (int64_t)ntl * (kT * kT);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 4 <= ksplit; k += 4) {
+        s0 += p[(k + 0) * stride];
+        s1 += p[(k + 1) * stride];
+        s2 += p[(k + 2) * stride];
+        s3 += p[(k + 3) * stride];
     }
+    for (; k < ksplit; ++k) s0 += p[k * stride];
+    double s = alpha * ((s0 + s1) + (s2 + s3));
+    if (bias) s += bias[j];
+    C[(int64_t)i * ldc + j] = s;
 }
 
 // ------------------------------------------------------------------ small helpers -------
@@ -690,7 +701,7 @@ extern "C" int vt_gemm_tn(const double* A, int64_t lda, int Da, const double* B,
     } else {
         hipLaunchKernelGGL(k_syrk_tile<true>, dim3(ntl, ks), dim3(256), 0, st, a);
     }
-    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3(ntl), dim3(1024), 0, st, (const double*)ws, ntb, ntl, ks, Da, Db, alpha,
-                       bias, C, ldc);
+    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3(kT * kT / 256, ntl), dim3(256), 0, st, (const double*)ws, ntb, ntl, ks,
+                       Da, Db, alpha, bias, C, ldc);
     return vt_launch_status();
 }

@@ -46,11 +46,19 @@ def all_reduce_sum(tensors, group):
     import torch.distributed as dist
     single = isinstance(tensors, torch.Tensor)
     ts = [tensors] if single else list(tensors)
-    if len(ts) == 1:
+    # a CPU-only backend (gloo: tests, one-GPU rehearsals of the multi-rank path) gets device
+    # tensors staged through the host; RCCL reduces them in place over xGMI
+    staged = ts[0].is_cuda and dist.get_backend(group) != "nccl"
+    if len(ts) == 1 and not staged:
         dist.all_reduce(ts[0], op=dist.ReduceOp.SUM, group=group)
     else:
         flat = torch.cat([t.reshape(-1) for t in ts])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if staged:
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat = host.to(ts[0].device)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         off = 0
         for t in ts:
             n = t.numel()
