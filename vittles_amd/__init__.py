@@ -8,6 +8,7 @@ from .objectives import RegisteredObjective, WeightedGLMObjective, HierGaussMFVI
 from .sparse_hessian_lib import SparseBlockHessian
 from .lr_cov_lib import LinearResponseCovariances
 from . import solver_lib
+from . import optim
 from . import bivariate_sensitivity_lib
 
 
@@ -29,5 +30,6 @@ __all__ = [
     "LinearResponseCovariances",
     "ParametricSensitivityTaylorExpansion",
     "solver_lib",
+    "optim",
     "bivariate_sensitivity_lib",
 ]

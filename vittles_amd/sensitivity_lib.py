@@ -23,6 +23,55 @@ from . import solver_lib
 from .objectives import RegisteredObjective, LazyCrossHessian
 
 
+def get_linear_function(return_val0, arg_val0, dreturn_darg_rows):
+    """Reference: ``get_linear_function`` (sensitivity_lib.py:18-82): a differentiable function
+    that returns ``return_val0`` when evaluated at ``arg_val0`` and whose Jacobian is the
+    pre-computed ``dreturn_darg``.  The reference registers an autograd primitive with
+    ``vjp(g) = g.T @ dreturn_darg`` (:60-68) and ``jvp(g) = dreturn_darg @ g`` (:73-76); this is
+    the same thing as a ``torch.autograd.Function`` (reverse AND forward mode), both products
+    being one streaming pass over the device-resident Jacobian.
+
+    ``dreturn_darg_rows``: the Jacobian TRANSPOSED, (len(arg), len(return)) row-major on the
+    device (how the sensitivity matrix is stored).  As in the reference the function must be
+    evaluated at ``arg_val0`` (ValueError otherwise) and is only once differentiable."""
+    from torch.autograd.function import once_differentiable
+    from . import rows
+    devc = dreturn_darg_rows.device
+    ret0 = dev.to_device(return_val0, devc)
+    arg0 = dev.to_device(arg_val0, devc)
+
+    def _check_arg_par_value(arg_par, tolerance=1e-8):
+        if arg_par.shape != arg0.shape or float((arg_par - arg0).abs().max().item()) > tolerance:
+            raise ValueError('get_return_par must be evaluated at ', arg_val0, ' != ', arg_par)
+
+    class _ReturnPar(torch.autograd.Function):
+        @staticmethod
+        def forward(arg_par):
+            return ret0.clone()
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            pass
+
+        @staticmethod
+        @once_differentiable
+        def backward(ctx, g):
+            return rows.gemv(dreturn_darg_rows, g.to(torch.float64).contiguous())     # g.T @ J
+
+        @staticmethod
+        def jvp(ctx, t):
+            return rows.gemv_t(dreturn_darg_rows, t.to(torch.float64).contiguous())   # J @ t
+
+    def get_return_par(arg_par):
+        if isinstance(arg_par, torch.Tensor):
+            _check_arg_par_value(arg_par.detach().to(devc))
+            return _ReturnPar.apply(arg_par.to(devc))
+        _check_arg_par_value(dev.to_device(arg_par, devc))
+        return dev.like_input(ret0.clone(), arg_par)
+
+    return get_return_par
+
+
 def _len(x):
     return x.shape[0] if hasattr(x, "shape") else len(x)
 
@@ -150,9 +199,9 @@ class EstimatingEquationLinearApproximation:
         return dev.like_input(out.t(), self._input_val0)
 
     def get_input_par_function(self):
-        raise NotImplementedError(
-            'get_input_par_function builds an autograd primitive in the reference '
-            '(sensitivity_lib.py:18-82); autograd is out of scope for this build.')
+        """Reference :249-254: the optimum as a differentiable function of the hyper-parameter
+        (a ``torch.autograd.Function`` here instead of an autograd primitive)."""
+        return get_linear_function(self._input_val0, self._hyper_val0, self._sens_rows)
 
 
 class HyperparameterSensitivityLinearApproximation(EstimatingEquationLinearApproximation):
