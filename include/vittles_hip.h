@@ -157,6 +157,24 @@ int    vt_glm_hvp(const double* X_dev, int64_t ldx, const double* d_dev, const d
 int    vt_gemv_t(const double* A_dev, int64_t lda, const double* u_dev, int64_t N, int D,
                  double* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* out (D,) = A^T (u1 .* u2): first-order Taylor right-hand side  (d^2 f / d theta d w) dw = X^T (r .* dw).
+ * Replaces: the order-1 term of ParametricSensitivityTaylorExpansion._evaluate_dkinput_dhyperk
+ *             vittles/sensitivity_lib.py:1209-1260 (forward-mode jvp of the estimating equation). */
+int    vt_gemv_t2(const double* A_dev, int64_t lda, const double* u1_dev, const double* u2_dev, int64_t N, int D,
+                  double* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* Second-order data-weight term of a GLM, one pass over X:
+ *   out (D,) = scale * sum_n [ w_n ell'''(z_n) (x_n.u)^2 + 2 dw_n ell''(z_n) (x_n.u) ] x_n
+ * = G_{theta theta}[u, u] + 2 G_{theta w}[u, dw] for the estimating equation G = grad_theta f (f is linear
+ * in w, so G_{ww} = 0); with u = d theta-hat/dw . dw the second directional derivative of the optimum is
+ * -H^{-1} out.  z_dev is vt_glm_link's z output.
+ * Replaces: the order-2 terms summed by ParametricSensitivityTaylorExpansion._evaluate_dkinput_dhyperk
+ *             vittles/sensitivity_lib.py:1209-1260 (terms from _get_taylor_base_terms / DerivativeTerm.differentiate,
+ *             :495-688), each a nested autograd.make_jvp of the gradient. */
+int    vt_glm_taylor2_rhs(int family, const double* X_dev, int64_t ldx, const double* z_dev, const double* w_dev,
+                          const double* dw_dev, double scale, const double* u_dev, int64_t N, int D,
+                          double* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
 /* K9, many weight vectors at once:  C (Da, Db) = alpha * A^T diag(s) B + 1 bias^T  for row-major
  * A (N, Da), B (N, Db); s (N,) and bias (Db,) may be NULL.  fp64 MFMA, N axis split over the chip,
  * fixed-order reduction.  With A = the matrix whose COLUMNS are new weight vectors (bootstrap draws,

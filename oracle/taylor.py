@@ -1,0 +1,64 @@
+"""ORACLE (test infrastructure, never a product path): the first two directional derivatives
+of the optimum in the data weights, restating what
+``ParametricSensitivityTaylorExpansion`` (``/root/reference/vittles/sensitivity_lib.py:1021-1363``)
+evaluates for the registered weighted-GLM objective.
+
+The reference Taylor-expands the estimating equation ``G(theta, w) = grad_theta f`` with nested
+``autograd.make_jvp`` calls and solves, order by order (``_evaluate_dkinput_dhyperk``, :1209-1260),
+
+    d^k theta = -H^{-1} ( sum of all order-k terms that do not contain d^k theta itself ).
+
+For ``f = scale * sum_n w_n ell(x_n.theta + off_n, y_n) + prior`` (linear in w):
+    order 1 (:_get_taylor_base_terms, 1007-1018):  G_w[dw]               = X^T (scale ell' .* dw)
+    order 2 (DerivativeTerm.differentiate, 575-640): G_tt[d1, d1] + 2 G_tw[d1, dw]
+            = X^T ( scale * (w ell''' t^2 + 2 dw ell'' t) ),   t = X d1.
+``evaluate_taylor_series`` (:1303-1342) then sums ``theta0 + d1 + d2 / 2``.
+"""
+import numpy as np
+import scipy.linalg
+
+from . import glm
+
+
+def link3(family, z):
+    """ell''(z), ell'''(z)."""
+    if family == "logistic":
+        p = glm._sigmoid(z)
+        l2 = p * (1.0 - p)
+        return l2, l2 * (1.0 - 2.0 * p)
+    if family == "poisson":
+        ez = np.exp(z)
+        return ez, ez
+    if family == "gaussian":
+        return np.ones_like(z), np.zeros_like(z)
+    raise ValueError(family)
+
+
+def input_derivs(family, X, y, theta, w, dw, prior=None, scale=1.0, offset=None, max_order=2):
+    """[d theta/dw . dw,  d^2 theta/dw^2 [dw, dw]] at (theta, w) (reference: evaluate_input_derivs,
+    sensitivity_lib.py:1273-1285)."""
+    if max_order not in (1, 2):
+        raise ValueError("oracle covers orders 1 and 2")
+    z = glm.linear_predictor(X, theta, offset)
+    _, l1, _ = glm.link(family, z, y)
+    l2, l3 = link3(family, z)
+    chol = scipy.linalg.cho_factor(glm.hessian(family, X, y, theta, w, prior, scale, offset))
+    d1 = -scipy.linalg.cho_solve(chol, X.T @ (scale * l1 * dw))
+    out = [d1]
+    if max_order >= 2:
+        t = X @ d1
+        rhs = X.T @ (scale * (w * l3 * t * t + 2.0 * dw * l2 * t))
+        out.append(-scipy.linalg.cho_solve(chol, rhs))
+    return out
+
+
+def taylor_series(family, X, y, theta, w, w_new, prior=None, scale=1.0, offset=None, max_order=2,
+                  add_offset=True):
+    """``evaluate_taylor_series`` (sensitivity_lib.py:1303-1342)."""
+    ds = input_derivs(family, X, y, theta, w, w_new - w, prior, scale, offset, max_order)
+    total = theta.copy() if add_offset else np.zeros_like(theta)
+    fact = 1.0
+    for k, d in enumerate(ds, start=1):
+        fact *= k
+        total = total + d / fact
+    return total

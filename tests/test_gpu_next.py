@@ -127,3 +127,76 @@ def test_opt_par_function_glm_vjp_jvp(relerr):
         dual = fwad.make_dual(w_t.detach(), torch.tensor(t, device="cuda"))
         tangent = fwad.unpack_dual(fn(dual)).tangent
     assert relerr(tangent.cpu().numpy(), S_ref @ t) < 1e-10
+
+
+# ---------------------------------------------------------------- rank 4: second-order data-weight terms -------
+@pytest.mark.parametrize("family", ["logistic", "poisson", "gaussian"])
+@pytest.mark.parametrize("N,D", [(300, 4), (5000, 33), (20000, 100)])
+def test_taylor_expansion_orders_1_2_match_oracle(family, N, D, relerr):
+    """ParametricSensitivityTaylorExpansion.optimization_objective for data weights
+    (vittles/sensitivity_lib.py:1021-1363) against oracle/taylor.py, 1e-10."""
+    import vittles_amd as va
+    from oracle import glm, taylor
+    X, y, w, _ = glm.synth(N, D, family, seed=N + 1)
+    rng = np.random.default_rng(5)
+    w = 0.5 + rng.random(N)
+    dw = rng.random(N) - 0.5
+    prior = np.linspace(0.5, 2.0, D)
+    theta = glm.newton_optimum(family, X, y, w, prior=prior, scale=1.5)
+    obj = va.WeightedGLMObjective(X, y, family=family, prior=prior, scale=1.5)
+    te = va.ParametricSensitivityTaylorExpansion.optimization_objective(
+        objective_function=obj, input_val0=theta, hyper_val0=w, order=2)
+    assert te.get_max_order() == 2
+    d_ref = taylor.input_derivs(family, X, y, theta, w, dw, prior, 1.5)
+    d_got = te.evaluate_input_derivs(dw)
+    assert len(d_got) == 2 and all(isinstance(d, np.ndarray) for d in d_got)
+    assert relerr(d_got[0], d_ref[0]) < 1e-10
+    if np.abs(d_ref[1]).max() > 0:
+        assert relerr(d_got[1], d_ref[1]) < 1e-10
+    for mo in (1, 2):
+        ref = taylor.taylor_series(family, X, y, theta, w, w + dw, prior, 1.5, max_order=mo)
+        assert relerr(te.evaluate_taylor_series(w + dw, max_order=mo), ref) < 1e-10
+    assert relerr(te.evaluate_taylor_series(w + dw, add_offset=False),
+                  taylor.taylor_series(family, X, y, theta, w, w + dw, prior, 1.5, add_offset=False)) < 1e-10
+    # the first-order term is the linear approximation's prediction (sensitivity_lib.py:245-247)
+    la = va.HyperparameterSensitivityLinearApproximation(obj, theta, w)
+    assert relerr(te.evaluate_taylor_series(w + dw, max_order=1), la.predict_opt_par_from_hyper_par(w + dw)) < 1e-10
+    with pytest.raises(ValueError):
+        te.evaluate_taylor_series(w + dw, max_order=3)
+    with pytest.raises(ValueError):
+        te.evaluate_taylor_series(w + dw, max_order=0)
+
+
+def test_taylor_expansion_reference_regression_kat():
+    """vittles/tests/test_sensitivity_lib.py:838-901 (orders 1 and 2 of its four), 6 decimals as there:
+    f = sum_n w_n (y_n - x_n theta)^2 is the gaussian family with scale 2 and no prior."""
+    import torch
+    import vittles_amd as va
+    rng = np.random.default_rng(0)
+    n_obs, dim = 10, 2
+    x = rng.random((n_obs, dim))
+    y = x @ np.array([0.5, -0.1]) + rng.normal(size=n_obs)
+    xt, yt = torch.tensor(x), torch.tensor(y)
+
+    def run(w):
+        # (X^T W X)^{-1} X^T W y by Cramer's rule (dim = 2): nested forward-mode AD through
+        # torch.linalg.solve returns HALF the second derivative (checked against finite differences)
+        a = torch.einsum('n,ni,nj->ij', w, xt, xt)
+        b = torch.einsum('n,ni,n->i', w, xt, yt)
+        det = a[0, 0] * a[1, 1] - a[0, 1] * a[1, 0]
+        return torch.stack([a[1, 1] * b[0] - a[0, 1] * b[1], a[0, 0] * b[1] - a[1, 0] * b[0]]) / det
+    w1 = torch.ones(n_obs, dtype=torch.float64)
+    dw = torch.tensor(rng.random(n_obs) - 0.5)
+    theta0 = run(w1).numpy()
+    d1_fn = lambda w: torch.func.jvp(run, (w,), (dw,))[1]
+    d1 = d1_fn(w1).numpy()
+    d2 = torch.func.jvp(d1_fn, (w1,), (dw,))[1].numpy()
+    obj = va.WeightedGLMObjective(x, y, family="gaussian", prior=None, scale=2.0)
+    te = va.ParametricSensitivityTaylorExpansion.optimization_objective(
+        objective_function=obj, input_val0=theta0, hyper_val0=w1.numpy(), order=2,
+        max_hyper_order=1, max_input_order=2, forward_mode=False)
+    w_new = (w1 + dw).numpy()
+    np.testing.assert_array_almost_equal(te.evaluate_taylor_series(w_new, max_order=1), theta0 + d1)
+    np.testing.assert_array_almost_equal(te.evaluate_taylor_series(w_new, max_order=2), theta0 + d1 + d2 / 2.0)
+    with pytest.raises(NotImplementedError):
+        va.ParametricSensitivityTaylorExpansion.optimization_objective(obj, theta0, w1.numpy(), order=4)

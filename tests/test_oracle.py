@@ -270,3 +270,78 @@ def test_vi_model_exactness():
     lr = lr_cov.LinearResponseCovariances(m.grad, m.hessian, eta, validate_optimum=True, grad_tol=1e-8)
     cov = lr.get_lr_covariance_from_jacobians(J, J)
     assert np.abs(cov - np.linalg.inv(P)).max() < 1e-12
+
+
+# ---- second-order data-weight terms -----------------------------
+def test_taylor_oracle_weighted_regression_kat():
+    """tests/test_sensitivity_lib.py:838-901: Taylor terms of theta(w) for weighted least squares
+    equal the directional derivatives of the closed form (X^T W X)^{-1} X^T W y -- here through
+    torch.func.jvp (nested once) in the role of the reference's `_append_jvp`; 6 decimals there,
+    1e-10 here."""
+    import torch
+    from oracle import taylor
+    rng = np.random.default_rng(0)
+    n_obs, dim = 10, 2
+    x = rng.random((n_obs, dim))
+    y = x @ np.array([0.5, -0.1]) + rng.normal(size=n_obs)
+    xt, yt = torch.tensor(x), torch.tensor(y)
+
+    def run(w):
+        # (X^T W X)^{-1} X^T W y by Cramer's rule (dim = 2): nested forward-mode AD through
+        # torch.linalg.solve returns HALF the second derivative (checked against finite differences)
+        a = torch.einsum('n,ni,nj->ij', w, xt, xt)
+        b = torch.einsum('n,ni,n->i', w, xt, yt)
+        det = a[0, 0] * a[1, 1] - a[0, 1] * a[1, 0]
+        return torch.stack([a[1, 1] * b[0] - a[0, 1] * b[1], a[0, 0] * b[1] - a[1, 0] * b[0]]) / det
+    w1 = torch.ones(n_obs, dtype=torch.float64)
+    dw = torch.tensor(rng.random(n_obs) - 0.5)
+    theta0 = run(w1).numpy()
+    d1_fn = lambda w: torch.func.jvp(run, (w,), (dw,))[1]
+    d1 = d1_fn(w1).numpy()
+    d2 = torch.func.jvp(d1_fn, (w1,), (dw,))[1].numpy()
+    got = taylor.input_derivs("gaussian", x, y, theta0, w1.numpy(), dw.numpy(), prior=None, scale=2.0)
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    assert rel(got[0], d1) < 1e-10 and rel(got[1], d2) < 1e-10
+    series = taylor.taylor_series("gaussian", x, y, theta0, w1.numpy(), (w1 + dw).numpy(), None, 2.0)
+    assert rel(series, theta0 + d1 + d2 / 2.0) < 1e-12
+
+
+@pytest.mark.parametrize("family", glm.FAMILIES)
+def test_taylor_oracle_vs_torch_ad_of_the_estimating_equation(family):
+    """The closed-form order-2 right-hand side == nested forward-mode AD of grad_theta f (what the
+    reference's DerivativeTerm machinery evaluates), and the resulting d2 == a central second
+    difference of the re-optimised optimum along w + t dw (loose: 1e-5)."""
+    import torch
+    from oracle import taylor
+    N, D = 150, 5
+    X, y, w, _ = glm.synth(N, D, family, seed=4)
+    rng = np.random.default_rng(1)
+    w = 0.5 + rng.random(N)
+    dw = 0.2 * (rng.random(N) - 0.5)
+    prior = np.linspace(0.5, 2, D)
+    theta = glm.newton_optimum(family, X, y, w, prior=prior, scale=1.3)
+    Xt, yt, pt = (torch.tensor(a) for a in (X, y, prior))
+
+    def f(t, ww):
+        z = Xt @ t
+        if family == "logistic":
+            ell = torch.nn.functional.softplus(z) - yt * z
+        elif family == "poisson":
+            ell = torch.exp(z) - yt * z
+        else:
+            ell = 0.5 * (z - yt) ** 2
+        return 1.3 * (ww * ell).sum() + 0.5 * (pt * t ** 2).sum()
+    G = torch.func.grad(f, 0)
+    d1, d2 = taylor.input_derivs(family, X, y, theta, w, dw, prior, 1.3)
+    tt, wt, dwt, d1t = (torch.tensor(a) for a in (theta, w, dw, d1))
+    # second total derivative of G along (theta + s d1, w + s dw) minus the H d2 term
+    path = lambda s: G(tt + s * d1t, wt + s * dwt)
+    first = lambda s: torch.func.jvp(path, (s,), (torch.ones((), dtype=torch.float64),))[1]
+    second = torch.func.jvp(first, (torch.zeros((), dtype=torch.float64),), (torch.ones((), dtype=torch.float64),))[1]
+    H = glm.hessian(family, X, y, theta, w, prior, 1.3)
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    assert rel(-H @ d2, second.numpy()) < 1e-10
+    eps = 1e-3
+    opt = lambda ww: glm.newton_optimum(family, X, y, ww, prior=prior, scale=1.3, iters=50)
+    fd2 = (opt(w + eps * dw) - 2 * theta + opt(w - eps * dw)) / eps ** 2
+    assert rel(d2, fd2) < 1e-5

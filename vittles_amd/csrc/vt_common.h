@@ -112,6 +112,22 @@ __device__ __forceinline__ void vt_link(int family, double z, double y, double& 
     }
 }
 
+// Per-row higher link derivatives (independent of y): l2 = ell''(z), l3 = ell'''(z).
+__device__ __forceinline__ void vt_link3(int family, double z, double& l2, double& l3) {
+    if (family == VT_FAMILY_LOGISTIC) {
+        double e = vt_exp(-fabs(z));
+        double inv = vt_rcp(1.0 + e);
+        l2 = e * inv * inv;                               // p (1 - p)
+        double omp2 = (1.0 - e) * inv;                    // |1 - 2p| = (1 - e) / (1 + e)
+        l3 = z >= 0.0 ? -l2 * omp2 : l2 * omp2;           // p (1 - p) (1 - 2p)
+    } else if (family == VT_FAMILY_POISSON) {
+        l2 = l3 = vt_exp(z);
+    } else {
+        l2 = 1.0;
+        l3 = 0.0;
+    }
+}
+
 // Per-row loss value ell(z, y).
 __device__ __forceinline__ double vt_loss(int family, double z, double y) {
     if (family == VT_FAMILY_LOGISTIC) {

@@ -47,6 +47,31 @@ def gemv(A, v):
     return out
 
 
+def gemv_t2(A, u1, u2):
+    """out (D,) = A^T (u1 .* u2) for a row-major (N, D) CUDA tensor A."""
+    lib = dev.require_gpu()
+    A = _rowmajor(A)
+    N, D = A.shape
+    out = torch.empty(D, dtype=torch.float64, device=A.device)
+    ws = _workspace(D, A.device)
+    _lib.check(lib.vt_gemv_t2(A.data_ptr(), A.stride(0), u1.contiguous().data_ptr(), u2.contiguous().data_ptr(),
+                              N, D, out.data_ptr(), ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_gemv_t2")
+    return out
+
+
+def glm_taylor2_rhs(obj, z, w, dw, u):
+    """Second-order data-weight right-hand side of a WeightedGLMObjective (one pass over X):
+    scale * sum_n [w_n ell'''(z_n) (x_n.u)^2 + 2 dw_n ell''(z_n) (x_n.u)] x_n."""
+    lib = dev.require_gpu()
+    out = torch.empty(obj.D, dtype=torch.float64, device=obj.device)
+    ws = _workspace(obj.D, obj.device)
+    _lib.check(lib.vt_glm_taylor2_rhs(_lib.FAMILY[obj.family], obj.X.data_ptr(), obj.X.stride(0), z.data_ptr(),
+                                      w.contiguous().data_ptr(), dw.contiguous().data_ptr(), obj.scale,
+                                      u.contiguous().data_ptr(), obj.N, obj.D, out.data_ptr(), ws.data_ptr(),
+                                      ws.numel() * 8, dev.stream_ptr()), "vt_glm_taylor2_rhs")
+    return out
+
+
 _tn_ws_cache = {}
 
 

@@ -277,6 +277,142 @@ class HyperparameterSensitivityLinearApproximation(EstimatingEquationLinearAppro
         return super().get_input_par_function()
 
 
+class ParametricSensitivityTaylorExpansion:
+    """Reference: sensitivity_lib.py:1021-1363 -- the Taylor series of the optimum in the
+    hyper-parameter.  The reference expands an arbitrary estimating equation to arbitrary order
+    with nested ``autograd.make_jvp`` calls; this build covers what has a fixed kernel shape
+    (SURVEY.md section 8f, rank 4): **data weights of a registered ``WeightedGLMObjective``,
+    orders 1 and 2**, each order one streaming pass over X plus one Cholesky solve:
+
+        d1 = -H^{-1} X^T (r .* dw)
+        d2 = -H^{-1} X^T scale (w ell''' t^2 + 2 dw ell'' t),   t = X d1
+
+    Same constructor / classmethod arguments and methods as the reference; ``forward_mode``,
+    ``max_input_order``, ``max_hyper_order`` and ``force`` are accepted (the closed forms make
+    them moot: the objective is linear in the weights, so hyper-order is 1 by construction)."""
+
+    @classmethod
+    def optimization_objective(cls, objective_function, input_val0, hyper_val0, order, hess0=None,
+                               forward_mode=True, max_input_order=None, max_hyper_order=None,
+                               force=False):
+        # Reference :1031-1080.
+        from .objectives import WeightedGLMObjective
+        if not isinstance(objective_function, WeightedGLMObjective):
+            raise NotImplementedError(
+                'ParametricSensitivityTaylorExpansion needs a WeightedGLMObjective '
+                '(autograd is not part of this build).')
+        if hess0 is None:
+            hess0 = objective_function.hessian(dev.to_device(input_val0), dev.to_device(hyper_val0))
+        hess_solver = solver_lib.get_cholesky_solver(hess0)
+        return cls(estimating_equation=_GradOf(objective_function), input_val0=input_val0,
+                   hyper_val0=hyper_val0, order=order, hess_solver=hess_solver,
+                   forward_mode=forward_mode, max_input_order=max_input_order,
+                   max_hyper_order=max_hyper_order, force=force)
+
+    def __init__(self, estimating_equation, input_val0, hyper_val0, order, hess_solver,
+                 forward_mode=True, max_input_order=None, max_hyper_order=None, force=False):
+        from . import rows
+        from .objectives import WeightedGLMObjective
+        obj = getattr(estimating_equation, '_obj', None)
+        if not isinstance(obj, WeightedGLMObjective):
+            raise NotImplementedError(
+                'estimating_equation must be the gradient of a WeightedGLMObjective '
+                '(autograd is not part of this build).')
+        if max_input_order is not None and max_input_order < 1:
+            raise ValueError('max_input_order must be >= 1.')
+        if max_hyper_order is not None and max_hyper_order < 1:
+            raise ValueError('max_hyper_order must be >= 1.')
+        if order < 1:
+            raise ValueError('order must be at least one.')
+        if order > 2:
+            raise NotImplementedError('Taylor orders above 2 are outside the MI355X hot path.')
+        self._obj = obj
+        self._input_val0 = deepcopy(input_val0)
+        self._hyper_val0 = deepcopy(hyper_val0)
+        self._objective_function_eta_grad = estimating_equation
+        self._order = order
+        self._max_input_order = max_input_order
+        self._max_hyper_order = max_hyper_order
+        self._forward_mode = forward_mode
+        self.hess_solver = hess_solver
+        self._theta = dev.to_device(input_val0, obj.device).contiguous()
+        self._w = dev.to_device(hyper_val0, obj.device).contiguous()
+        if self._theta.shape != (obj.D,) or self._w.shape != (obj.N,):
+            raise ValueError('input_val0 / hyper_val0 do not match the objective.')
+        # per-row linear predictor and first link derivative at the base point (one pass, kept)
+        self._z, self._r, _ = rows.glm_link(obj, self._theta, self._w, want_z=True)
+
+    def get_max_order(self):
+        return self._order
+
+    def _solve(self, vec):
+        chol = getattr(self.hess_solver, "cholesky", None)
+        if chol is not None:
+            return chol.solve(vec)
+        return dev.to_device(self.hess_solver(dev.like_input(vec, self._input_val0)), vec.device)
+
+    def _evaluate_dkinput_dhyperk(self, dhyper, input_derivs, k):
+        # Reference :1209-1260 (same checks, same ``-1 * hess_solver(vec)``).
+        from . import rows
+        if k <= 0:
+            raise ValueError('k must be at least one.')
+        if k > self._order:
+            raise ValueError('k must be no greater than the declared order={}'.format(self._order))
+        if len(input_derivs) < k - 1:
+            raise ValueError('Not enough eta_derivs provided.')
+        obj = self._obj
+        if k == 1:
+            vec = rows.gemv_t2(obj.X, self._r, dhyper)
+        else:
+            vec = rows.glm_taylor2_rhs(obj, self._z, self._w, dhyper, input_derivs[0])
+        obj._all_reduce(vec)            # row-sharded objective: partial sums over the ranks' rows
+        return -1 * self._solve(vec)
+
+    def _get_default_max_order(self, max_order):
+        # Reference :1262-1271.
+        if max_order is None:
+            return self._order
+        if max_order <= 0:
+            raise ValueError('max_order must be greater than zero.')
+        if max_order > self._order:
+            raise ValueError('max_order must be no greater than the order={}'.format(self._order))
+        return max_order
+
+    def _dev_derivs(self, dhyper, max_order):
+        dh = dev.to_device(dhyper, self._obj.device).contiguous()
+        if dh.shape != self._w.shape:
+            raise ValueError('dhyper has the wrong shape.')
+        derivs = []
+        for k in range(1, max_order + 1):
+            derivs.append(self._evaluate_dkinput_dhyperk(dh, derivs, k))
+        return derivs
+
+    def evaluate_input_derivs(self, dhyper, max_order=None):
+        """List of the directional derivatives ``d^k input / d hyper^k [dhyper, ...]`` (:1273-1285)."""
+        max_order = self._get_default_max_order(max_order)
+        return [dev.like_input(d, self._input_val0) for d in self._dev_derivs(dhyper, max_order)]
+
+    def evaluate_taylor_series_terms(self, new_hyper_val, add_offset=True, max_order=None):
+        # Reference :1288-1301.
+        max_order = self._get_default_max_order(max_order)
+        zero = torch.zeros_like(self._theta)
+        terms = [self._theta.clone() if add_offset else zero]
+        dhyper = dev.to_device(new_hyper_val, self._obj.device) - self._w
+        fact = 1.0
+        for k, d in enumerate(self._dev_derivs(dhyper, max_order), start=1):
+            fact *= k
+            terms.append(d / fact)
+        return [dev.like_input(t, self._input_val0) for t in terms]
+
+    def evaluate_taylor_series(self, new_hyper_val, add_offset=True, max_order=None, sum_terms=True):
+        # Reference :1303-1342 (which sums the terms whatever ``sum_terms`` says).
+        terms = self.evaluate_taylor_series_terms(new_hyper_val, add_offset=add_offset, max_order=max_order)
+        total = terms[0]
+        for t in terms[1:]:
+            total = total + t
+        return total
+
+
 class _GradOf:
     """``autograd.grad(objective, argnum=0)`` for a registered objective, carrying the
     Jacobian w.r.t. the hyper-parameter that the reference builds with
