@@ -25,6 +25,21 @@ class DeviceCholesky:
                 raise np.linalg.LinAlgError(
                     "%d-th leading minor of the array is not positive definite" % k)
 
+    def info_to_host_async(self, host_slot):
+        """Queue a copy of potrf's info into ``host_slot`` (a 1-element pinned int32 CPU tensor)
+        and return an event that completes when it has landed: lets a pipeline of factorisations
+        be checked one step late without draining the stream."""
+        host_slot.copy_(self._info, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    @staticmethod
+    def raise_for_info(k):
+        if k > 0:
+            raise np.linalg.LinAlgError(
+                "%d-th leading minor of the array is not positive definite" % k)
+
     # -- construction -----------------------------------------------------
     @classmethod
     def factor(cls, H, check=True, pack=False):

@@ -111,8 +111,13 @@ class WeightedGLMObjective(RegisteredObjective):
             raise _lib.VittlesHipError("vt_glm_hessian does not support D = %d" % self.D)
         if self._ws is None or self._ws.numel() * 8 < nbytes:
             self._ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=self.device)
-        H = torch.empty((self.D, self.D), dtype=torch.float64, device=self.device)
-        g = torch.empty(self.D, dtype=torch.float64, device=self.device)
+        # H and g are views of ONE buffer, so that the row-sharded path all-reduces a single
+        # message of D*D + D doubles in place (no gather / scatter copies around the collective)
+        # (g starts on a 256-byte boundary; the few padding doubles in between ride along)
+        goff = (self.D * self.D + 31) // 32 * 32
+        Hg = torch.empty(goff + self.D, dtype=torch.float64, device=self.device)
+        H = Hg[:self.D * self.D].view(self.D, self.D)
+        g = Hg[goff:]
         r = torch.empty(self.N, dtype=torch.float64, device=self.device)
         d = torch.empty(self.N, dtype=torch.float64, device=self.device)
         prior = self.prior if self._rank() == 0 else None
@@ -121,7 +126,7 @@ class WeightedGLMObjective(RegisteredObjective):
             self.y.data_ptr(), w.data_ptr(), dev.ptr(self.offset), self.scale, dev.ptr(prior),
             self.N, self.D, H.data_ptr(), self.D, g.data_ptr(), r.data_ptr(), d.data_ptr(),
             self._ws.data_ptr(), self._ws.numel() * 8, dev.stream_ptr()), "vt_glm_hessian")
-        self._all_reduce([H, g])      # one RCCL message: D*D + D doubles
+        self._all_reduce(Hg)          # one RCCL message: D*D + D doubles
         out = dict(H=H, g=g, r=r, d=d, theta=theta, w=w)
         self._cache_key, self._cache = key, out
         return out
