@@ -112,6 +112,11 @@ int    vt_trsm_pack(const double* L_dev, int ldl, int D, void* pack_dev, void* s
  * factorisation): A <- L in place, *info_dev as vt_potrf, pack_dev as vt_trsm_pack.
  * Replaces: scipy.linalg.cho_factor(h)   vittles/solver_lib.py:26-27 */
 int    vt_potrf_pack(double* A_dev, int lda, int D, int* info_dev, void* pack_dev, void* stream);
+/* The same, out of place: H_dev is left untouched (the reference keeps `self._hess0` for
+ * get_hessian_at_opt(), vittles/sensitivity_lib.py:385, 411-412), L_dev gets the factor in its lower
+ * triangle and zeros above it.  Saves the copy an in-place factorisation needs. */
+int    vt_potrf_pack_from(const double* H_dev, int ldh, double* L_dev, int ldl, int D, int* info_dev,
+                          void* pack_dev, void* stream);
 
 /* Out[n,:] = alpha * s_n * H^{-1} B[n,:]   for n < N  (s_n = 1 if rowscale_dev NULL)
  * Replaces: `-1 * self._hess_solver(self._estimating_equation_jac0)`

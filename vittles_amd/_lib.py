@@ -37,6 +37,7 @@ SIGNATURES = {
     "vt_trsm_pack_bytes": (c_size_t, [c_int]),
     "vt_trsm_pack": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr]),
     "vt_potrf_pack": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+    "vt_potrf_pack_from": (c_int, [c_ptr, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "vt_trsm_rows": (c_int, [c_ptr, c_int, c_ptr, c_i64, c_ptr, c_dbl, c_i64, c_ptr, c_i64, c_ptr]),
     "vt_rows_workspace_bytes": (c_size_t, [c_int]),
     "vt_glm_link": (c_int, [c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_i64, c_int,

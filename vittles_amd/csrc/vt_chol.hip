@@ -31,23 +31,33 @@ __host__ __device__ __forceinline__ int vt_perm(bool permuted, int p) {
     return permuted ? (4 * (p & 3) + (p >> 2)) : p;
 }
 
-// mode bit 0: factor A in place (else A already holds L);  pack != NULL: also emit the TRSM pack.
-__global__ __launch_bounds__(256) void k_potrf_pack_small(double* A, int lda, int D, int* info, double* pack,
-                                                         int do_factor) {
+// do_factor: factor the matrix at Ain (leading dimension ldin) into A (Ain == A: in place; otherwise A
+// also gets a zero strict upper triangle), else A already holds L;  pack != NULL: also emit the TRSM pack.
+__global__ __launch_bounds__(256) void k_potrf_pack_small(const double* Ain, int ldin, double* A, int lda, int D,
+                                                         int* info, double* pack, int do_factor) {
     __shared__ double a[VT_SMALL_D_MAX * kSmallLd];
     __shared__ double linv[8 * 16 * 17];
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NB = (D + 15) >> 4, NP = NB * 16, NBT = NB * (NB + 1) / 2;
     if (tid == 0) s_bad = 0;
-    // zero-padded lower triangle -> LDS (identity on the padding diagonal); 128 threads per row
-    for (int i = tid >> 7; i < NP; i += 2) {
+    // zero-padded lower triangle -> LDS (identity on the padding diagonal); 128 threads per row, 8 rows'
+    // loads in flight per thread (unconditional, clamped: a predicated load drains vmcnt every iteration)
+    {
         const int j = tid & 127;
-        if (j < NP) {
-            double v = 0.0;
-            if (i < D && j <= i) v = A[(int64_t)i * lda + j];
-            if (i >= D && j == i) v = 1.0;
-            a[i * kSmallLd + j] = v;
+        const int jc = j < D ? j : D - 1;
+        for (int i0 = tid >> 7; i0 < NP; i0 += 16) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 2 * u;
+                v[u] = Ain[(int64_t)(i < D ? i : D - 1) * ldin + jc];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 2 * u;
+                if (i < NP && j < NP) a[i * kSmallLd + j] = (i < D && j <= i) ? v[u] : ((i >= D && j == i) ? 1.0 : 0.0);
+            }
         }
     }
     __syncthreads();
@@ -172,46 +182,53 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(double* A, int lda, in
     __syncthreads();
     const int bad = s_bad;
     if (do_factor) {
+        const bool oop = Ain != A;
         for (int i = tid >> 7; i < D; i += 2) {
             const int j = tid & 127;
             if (j <= i) A[(int64_t)i * lda + j] = a[i * kSmallLd + j];
+            else if (oop && j < D) A[(int64_t)i * lda + j] = 0.0;
         }
         if (tid == 0 && info) *info = bad;
     }
     if (pack == nullptr || bad || (VT_PABL & 8)) return;
-    // ---- TRSM operand pack (see vt_trsm_pack) ---------------------------------------------
+    // ---- TRSM operand pack (see vt_trsm_pack), one block pair per wave at a time, on the MFMA:
+    //      forward  F_ji = -Linv_jj L_ji,  backward  B_ji = -Linv_jj^T L_ij^T  (16x16x16 products), the
+    //      accumulator element (row, col) scattered to its slot of the A-operand image -----------------
     const bool lastperm = (D & 15) == 0;
-    const int total = 2 * NBT * 256;
-    for (int e = tid; e < total; e += 256) {
-        int PI = e >> 8, sstep = (e >> 6) & 3, ln = e & 63;
-        int q = ln >> 4, rho = ln & 15;
-        bool bwd = PI >= NBT;
-        int t = bwd ? PI - NBT : PI;
+    const int q = lane >> 4, c = lane & 15;
+    for (int PI = wave; PI < 2 * NBT; PI += 4) {
+        const bool bwd = PI >= NBT;
+        const int t = bwd ? PI - NBT : PI;
         int hi = 0;
         while ((hi + 1) * (hi + 2) / 2 <= t) ++hi;
-        int lo = t - hi * (hi + 1) / 2;
-        int j = bwd ? lo : hi, i = bwd ? hi : lo;
-        int row = vt_perm(j < NB - 1 || lastperm, rho);
-        int col = vt_perm(i < NB - 1 || lastperm, 4 * sstep + q);
-        double v;
-        if (!bwd) {
-            if (i == j) {
-                v = linv[(j * 16 + row) * 17 + col];
-            } else {
-                v = 0.0;
-                for (int m = 0; m < 16; ++m)
-                    v -= linv[(j * 16 + row) * 17 + m] * a[(16 * j + m) * kSmallLd + 16 * i + col];
-            }
+        const int lo = t - hi * (hi + 1) / 2;
+        const int j = bwd ? lo : hi, i = bwd ? hi : lo;
+        f64x4 m = {0.0, 0.0, 0.0, 0.0};
+        if (i == j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                m[r] = bwd ? linv[(j * 16 + c) * 17 + q + 4 * r] : linv[(j * 16 + q + 4 * r) * 17 + c];
         } else {
-            if (i == j) {
-                v = linv[(j * 16 + col) * 17 + row];
-            } else {
-                v = 0.0;
-                for (int m = 0; m < 16; ++m)
-                    v -= linv[(j * 16 + m) * 17 + row] * a[(16 * i + col) * kSmallLd + 16 * j + m];
+            double av[4], bv[4];
+#pragma unroll
+            for (int sstep = 0; sstep < 4; ++sstep) {
+                const int k = 4 * sstep + q;
+                if (!bwd) {
+                    av[sstep] = -linv[(j * 16 + c) * 17 + k];
+                    bv[sstep] = a[(16 * j + k) * kSmallLd + 16 * i + c];
+                } else {
+                    av[sstep] = -linv[(j * 16 + k) * 17 + c];
+                    bv[sstep] = a[(16 * i + c) * kSmallLd + 16 * j + k];
+                }
             }
+#pragma unroll
+            for (int sstep = 0; sstep < 4; ++sstep) m = mfma_f64(av[sstep], bv[sstep], m);
         }
-        pack[e] = v;
+        const bool pj = j < NB - 1 || lastperm, pi = i < NB - 1 || lastperm;
+        const int kk = vt_perm(pi, c);                     // vt_perm is an involution
+        double* dst = pack + ((int64_t)PI * 4 + (kk >> 2)) * 64 + (kk & 3) * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[vt_perm(pj, q + 4 * r)] = m[r];
     }
 }
 
@@ -514,7 +531,8 @@ int dispatch_trsm_kl(const TrsmArgs& a, hipStream_t st) {
 }  // namespace
 
 int vt_potrf_pack_block(double* A, int lda, int D, int* info, double* pack, int do_factor, hipStream_t st) {
-    hipLaunchKernelGGL(k_potrf_pack_small, dim3(1), dim3(256), 0, st, A, lda, D, info, pack, do_factor);
+    hipLaunchKernelGGL(k_potrf_pack_small, dim3(1), dim3(256), 0, st, (const double*)A, lda, A, lda, D, info, pack,
+                       do_factor);
     return vt_launch_status();
 }
 
@@ -592,6 +610,21 @@ extern "C" int vt_potrf_pack(double* A, int lda, int D, int* info, void* pack, v
         return vt_large_pack(A, lda, D, pack, (hipStream_t)stream);
     }
     return vt_potrf_pack_block(A, lda, D, info, (double*)pack, 1, (hipStream_t)stream);
+}
+
+extern "C" int vt_potrf_pack_from(const double* H, int ldh, double* L, int ldl, int D, int* info, void* pack,
+                                  void* stream) {
+    if (!H || !L || !info || !pack || D < 1 || ldh < D || ldl < D) return VT_ERR_BAD_ARG;
+    if (D > kLargeDMax) return VT_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (D > VT_SMALL_D_MAX || (const double*)L == H) {
+        if ((const double*)L != H)
+            VT_CHECK_HIP(hipMemcpy2DAsync(L, (size_t)ldl * sizeof(double), H, (size_t)ldh * sizeof(double),
+                                          (size_t)D * sizeof(double), D, hipMemcpyDeviceToDevice, st));
+        return vt_potrf_pack(L, ldl, D, info, pack, stream);
+    }
+    hipLaunchKernelGGL(k_potrf_pack_small, dim3(1), dim3(256), 0, st, H, ldh, L, ldl, D, info, (double*)pack, 1);
+    return vt_launch_status();
 }
 
 extern "C" int vt_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale,

@@ -50,15 +50,19 @@ class DeviceCholesky:
         D = H.shape[0]
         if H.ndim != 2 or H.shape[1] != D:
             raise ValueError('Input array needs to be a square matrix.')
-        L = H.detach().clone().contiguous()
-        info = torch.empty(1, dtype=torch.int32, device=L.device)
+        info = torch.empty(1, dtype=torch.int32, device=H.device)
         pk = None
         if pack and lib.vt_trsm_pack_bytes(D) > 0:
-            # one launch: blocked Cholesky + the MFMA TRSM operand images
+            # one launch, out of place: blocked Cholesky + the MFMA TRSM operand images
+            Hs = H.detach()
+            if Hs.stride(1) != 1:
+                Hs = Hs.contiguous()
+            L = torch.empty((D, D), dtype=torch.float64, device=H.device)
             pk = torch.empty(lib.vt_trsm_pack_bytes(D) // 8, dtype=torch.float64, device=L.device)
-            _lib.check(lib.vt_potrf_pack(L.data_ptr(), D, D, info.data_ptr(), pk.data_ptr(), dev.stream_ptr()),
-                       "vt_potrf_pack")
+            _lib.check(lib.vt_potrf_pack_from(Hs.data_ptr(), Hs.stride(0), L.data_ptr(), D, D, info.data_ptr(),
+                                              pk.data_ptr(), dev.stream_ptr()), "vt_potrf_pack_from")
         else:
+            L = H.detach().clone().contiguous()
             nws = lib.vt_potrf_workspace_bytes(D)
             ws = torch.empty(nws // 8 + 1, dtype=torch.float64, device=L.device) if nws else None
             _lib.check(lib.vt_potrf(L.data_ptr(), D, D, info.data_ptr(), dev.ptr(ws), nws, dev.stream_ptr()),
