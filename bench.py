@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=500)
+    p.add_argument("--warmup", type=int, default=50)
     p.add_argument("--rows", type=int, default=1_000_000, help="rows per GPU")
     p.add_argument("--dim", type=int, default=100)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -89,6 +89,54 @@ def hvp_side_measurement(torch, device, n_rows, dim, reps=10):
     del X
     return {"kernel": "k_rows_wide<OP_HVP> (K6 fused HVP)", "rows": n_rows, "dim": dim, "ms": ms,
             "algorithmic_bytes": nbytes, "GBs": gbs, "peak_GBs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}
+
+
+def config1_side_measurement(torch):
+    """BASELINE.json configs[0] (N = 10k, D = 20, the reference's own CPU-runnable case), both ways:
+    the drop-in class on the GPU (host arrays in, host S out: construction to get_dopt_dhyper)
+    and an AD-structured CPU baseline with the reference's cost structure -- torch.func.hessian
+    + jacrev(grad, argnums=1) in fp64 (D + D reverse sweeps) + SciPy cho_factor / cho_solve --
+    standing in for `vittles` + `autograd`, which is not installed."""
+    import scipy.linalg
+    import vittles_amd as va
+    from oracle import glm
+    N, D = 10_000, 20
+    X, y, w, _ = glm.synth(N, D, "logistic", seed=0)
+    theta = glm.newton_optimum("logistic", X, y, w, prior=1.0)
+    obj = va.WeightedGLMObjective(X, y, family="logistic", prior=1.0)
+
+    def gpu():
+        obj._cache_key = None
+        la = va.HyperparameterSensitivityLinearApproximation(obj, theta, w)
+        return la.get_dopt_dhyper()
+    gpu()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        S_gpu = gpu()
+    gpu_ms = (time.perf_counter() - t0) / 5 * 1e3
+    Xt, yt = torch.tensor(X), torch.tensor(y)
+
+    def f(t, ww):
+        z = Xt @ t
+        return (ww * (torch.nn.functional.softplus(z) - yt * z)).sum() + 0.5 * (t * t).sum()
+
+    def cpu_ad():
+        tt, wt = torch.tensor(theta), torch.tensor(w)
+        H = torch.func.hessian(f, 0)(tt, wt).numpy()
+        jac0 = torch.func.jacrev(torch.func.grad(f, 0), 1)(tt, wt).numpy()
+        return -1 * scipy.linalg.cho_solve(scipy.linalg.cho_factor(H), jac0)
+    cpu_ad()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        S_ad = cpu_ad()
+    ad_ms = (time.perf_counter() - t0) / 3 * 1e3
+    err = float(np.abs(S_gpu - S_ad).max() / np.abs(S_ad).max())
+    return {"workload": "weighted logistic regression N=10000 D=20 (configs[0])",
+            "gpu_dropin_ms_host_to_host": gpu_ms, "gpu_sens_per_s": N / (gpu_ms * 1e-3),
+            "cpu_ad_baseline_ms": ad_ms, "cpu_ad_sens_per_s": N / (ad_ms * 1e-3),
+            "cpu_ad_kind": "torch.func.hessian + jacrev(grad, 1) fp64 + scipy cho_factor/cho_solve (stand-in for "
+                           "vittles+autograd, not installed)", "cpu_threads": torch.get_num_threads(),
+            "S_max_rel_err_gpu_vs_ad": err}
 
 
 def note(msg):
@@ -259,6 +307,7 @@ def main():
                     "S_max_rel_err": float(np.abs(Sg.T - S_cpu).max() / np.abs(S_cpu).max()),
                     "rows_checked": int(N), "tolerance": 1e-10}
             result["speedup_vs_cpu_baseline"] = value / base["value"]
+            result["config1"] = config1_side_measurement(torch)
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
