@@ -170,3 +170,20 @@ def test_row_kernels(relerr):
         val = obj(theta, w)
         ref = glm.value("logistic", X, y, theta, w, prior, 0.7, offset)
         assert abs(val - ref) <= TOL * abs(ref), (N, D)
+
+
+@pytest.mark.parametrize("D,K", [(1, 1), (20, 1), (100, 1), (100, 5), (128, 3)])
+def test_vt_potrs_generic_kernel_direct(D, K, relerr):
+    """The generic substitution kernel through the C-ABI (DeviceCholesky.solve routes small D to the
+    MFMA tile kernel, so it is called directly here)."""
+    torch = _torch()
+    from vittles_amd import _lib, device as dev
+    from vittles_amd.linalg import DeviceCholesky
+    rng = np.random.default_rng(D + K)
+    A = rng.standard_normal((D + 5, D))
+    H = A.T @ A + np.eye(D)
+    chol = DeviceCholesky.factor(torch.tensor(H, device="cuda"))
+    B = rng.standard_normal((D, K))
+    x = torch.tensor(B, device="cuda").contiguous()
+    _lib.check(_lib.load().vt_potrs(chol.L.data_ptr(), D, D, x.data_ptr(), K, 1, K, dev.stream_ptr()), "vt_potrs")
+    assert relerr(x.cpu().numpy(), np.linalg.solve(H, B)) < 1e-9

@@ -13,6 +13,8 @@ from . import optim
 from . import bivariate_sensitivity_lib
 
 
+__version__ = "0.1.0"
+
 __all__ = [
     "HyperparameterSensitivityLinearApproximation",
     "EstimatingEquationLinearApproximation",

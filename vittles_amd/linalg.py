@@ -88,13 +88,18 @@ class DeviceCholesky:
         if v.shape[0] != self.D:
             raise ValueError("incompatible dimensions: factor is %dx%d, b has %d rows"
                              % (self.D, self.D, v.shape[0]))
+        small = self.D <= _lib.SMALL_D_MAX
         if v.ndim == 1:
+            if small:
+                # one 16-row tile of the MFMA TRSM (pack resident in LDS): ~6x faster than the generic
+                # one-wave substitution for a single right-hand side
+                return self.solve_rows(v.detach().reshape(1, self.D)).reshape(self.D)
             x = v.detach().clone().contiguous()
             _lib.check(lib.vt_potrs(self.L.data_ptr(), self.D, self.D, x.data_ptr(), 1, self.D, 1,
                                     dev.stream_ptr()), "vt_potrs")
             return x
         K = v.shape[1]
-        if K >= 64 and lib.vt_trsm_pack_bytes(self.D) > 0:
+        if (small or K >= 64) and lib.vt_trsm_pack_bytes(self.D) > 0:
             # MFMA TRSM wants right-hand sides as rows: (K, D) row-major.
             rows = v.detach().t().contiguous()
             out = self.solve_rows(rows)
@@ -125,7 +130,10 @@ class DeviceCholesky:
             B = B.contiguous()
         if out is None:
             out = torch.empty((N, D), dtype=torch.float64, device=B.device)
-        _lib.check(lib.vt_trsm_rows(self.pack().data_ptr(), D, B.data_ptr(), B.stride(0),
-                                    dev.ptr(rowscale), float(alpha), N, out.data_ptr(), out.stride(0),
+        # a single row's stride is arbitrary (torch reports 1 for a transposed (D, 1) column)
+        ldb = B.stride(0) if N > 1 else D
+        ldo = out.stride(0) if N > 1 else D
+        _lib.check(lib.vt_trsm_rows(self.pack().data_ptr(), D, B.data_ptr(), ldb,
+                                    dev.ptr(rowscale), float(alpha), N, out.data_ptr(), ldo,
                                     dev.stream_ptr()), "vt_trsm_rows")
         return out

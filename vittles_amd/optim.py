@@ -51,7 +51,7 @@ def newton_glm(objective, hyper_par, opt_par_init=None, max_iter=50, grad_tol=1e
             converged = True
             it -= 1
             break
-        step = DeviceCholesky.factor(H).solve(g)            # K4 + K5; LinAlgError if H is not PD
+        step = DeviceCholesky.factor(H, pack=True).solve(g)  # K4 + K5; LinAlgError if H is not PD
         slope = float(torch.dot(g, step).item())            # > 0 for PD H
         # objective values carry rounding noise of a few ulps of |f|: once the predicted decrease
         # is below it the value test says nothing, and the full Newton step is taken
