@@ -531,26 +531,34 @@ inline size_t tile_lds_bytes(int NB) {
     return std::max(loop, tail) * sizeof(double);
 }
 
-// Sum `per` consecutive partial slabs into one: out[p][e] = sum_{k<per} in[p*per + k][e].
-__global__ void k_reduce_slabs(const double* in, double* out, int L, int P_in, int per) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    int p = blockIdx.y;
-    if (e >= L) return;
+// Final: sum ALL partial slabs (fixed order), undo the accumulator layout, mirror the triangle, add
+// the prior -- one launch.  A block owns 16 consecutive slab elements; its 16 thread groups each sum
+// every 16th slab (128-byte coalesced reads, four loads in flight), then group 0 adds the 16 partial
+// sums in order.
+__global__ __launch_bounds__(256) void k_hess_finalize(const double* in, int L, int P, int NB, int D,
+                                                       const double* prior, const double* theta,
+                                                       double* H, int ldh, double* g) {
+    __shared__ double sh[16][17];
+    const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (e < L) {
+        const double* p = in + e;
+        int k = grp;
+        for (; k + 48 < P; k += 64) {
+            s0 += p[(int64_t)k * L];
+            s1 += p[(int64_t)(k + 16) * L];
+            s2 += p[(int64_t)(k + 32) * L];
+            s3 += p[(int64_t)(k + 48) * L];
+        }
+        for (; k < P; k += 16) s0 += p[(int64_t)k * L];
+    }
+    sh[grp][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp != 0 || e >= L) return;
     double s = 0.0;
-    int k0 = p * per, k1 = min(P_in, k0 + per);
-    for (int k = k0; k < k1; ++k) s += in[(int64_t)k * L + e];
-    out[(int64_t)p * L + e] = s;
-}
-
-// Final: sum the remaining slabs, undo the accumulator layout, mirror the
-// triangle, add the prior.  One thread per accumulator element / gradient entry.
-__global__ void k_hess_finalize(const double* in, int L, int P, int NB, int D,
-                                const double* prior, const double* theta,
-                                double* H, int ldh, double* g) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= L) return;
-    double s = 0.0;
-    for (int k = 0; k < P; ++k) s += in[(int64_t)k * L + e];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += sh[q][el];
     int NBT = NB * (NB + 1) / 2;
     if (e < NBT * 256) {
         int blk = e >> 8, r = (e >> 6) & 3, lane = e & 63;
@@ -716,16 +724,7 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
         case 8: launch_hess_small<8>(a, grid, st); break;
         default: return VT_ERR_UNSUPPORTED;
     }
-    const double* fin = part;
-    int P = grid;
-    if (P > kStage2) {
-        int per = (P + kStage2 - 1) / kStage2;
-        int P2 = (P + per - 1) / per;
-        hipLaunchKernelGGL(k_reduce_slabs, dim3((L + 255) / 256, P2), dim3(256), 0, st, part, part2, L, P, per);
-        fin = part2;
-        P = P2;
-    }
-    hipLaunchKernelGGL(k_hess_finalize, dim3((L + 255) / 256), dim3(256), 0, st, fin, L, P, NB, D, prior, theta,
-                       H, ldh, g);
+    hipLaunchKernelGGL(k_hess_finalize, dim3((L + 15) / 16), dim3(256), 0, st, (const double*)part, L, grid, NB, D,
+                       prior, theta, H, ldh, g);
     return vt_launch_status();
 }
