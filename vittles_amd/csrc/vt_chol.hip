@@ -15,12 +15,14 @@ constexpr int kSmallLd = VT_SMALL_D_MAX + 1;  // odd stride: column walks are ba
 // One workgroup, matrix resident in LDS (D <= 128: 132 KB of the CU's 160 KB).
 // Latency-bound by construction (D^3/3 flops is nothing), so the budget is barriers and
 // dependent LDS round trips.  Blocked right-looking Cholesky with 16-wide panels:
-//   (a) wave 0 factors the 16x16 diagonal block AND inverts it entirely in registers
-//       (lane = row; cross-lane traffic is v_readlane with compile-time lane ids, no LDS),
-//   (b) one thread per row below solves its 16-entry panel row against the inverse,
-//   (c) the trailing blocks are updated with v_mfma_f64_16x16x4_f64 straight from LDS.
-// 3 barriers per panel (21 at D = 100) instead of 3 per column (300).  The inverted diagonal
-// blocks are exactly what the TRSM operand pack needs, so the same kernel emits the pack.
+//   (a) wave 0 factors the 16x16 diagonal block entirely in registers (lane = row; cross-lane
+//       traffic is v_readlane with compile-time lane ids, no LDS),
+//   (b) one thread per row below solves its 16-entry panel row by substitution against the block,
+//   (c) the trailing blocks are updated with v_mfma_f64_16x16x4_f64 straight from LDS -- wave 0
+//       takes the next diagonal block first and factors it (look-ahead) while the other waves do
+//       the rest of the update and wave 1 inverts the block just used: the inverted diagonal blocks
+//       are what the TRSM operand pack needs, and they never sit on the critical path.
+// 2 barriers per panel.  The same kernel emits the pack (16x16x16 products on the MFMA).
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -37,6 +39,7 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(const double* Ain, int
                                                          int* info, double* pack, int do_factor) {
     __shared__ double a[VT_SMALL_D_MAX * kSmallLd];
     __shared__ double linv[8 * 16 * 17];
+    __shared__ double rdiag_s[VT_SMALL_D_MAX];
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NB = (D + 15) >> 4, NP = NB * 16, NBT = NB * (NB + 1) / 2;
@@ -62,8 +65,9 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(const double* Ain, int
     }
     __syncthreads();
 
-    // (a) diagonal block J: factor (optional) + invert in registers, lane r = row r.  Wave 0 only.
-    auto diag_block = [&](int J) {
+    // (a) diagonal block J: factor in registers, lane r = row r (wave 0).  Leaves L_JJ in LDS and the
+    //     reciprocal pivots in rdiag_s.
+    auto diag_factor = [&](int J) __attribute__((always_inline)) {
         const int o = 16 * J;
         const int r = lane & 15;
         double row[16];
@@ -71,46 +75,49 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(const double* Ain, int
         for (int cc = 0; cc < 16; ++cc) row[cc] = a[(o + r) * kSmallLd + o + cc];
         int bad = 0;
         double rdiag[16];
-        if (do_factor) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                double akk = readlane_f64(row[k], k);
-                if (!(akk > 0.0) && bad == 0 && o + k < D) bad = o + k + 1;
-                // 1/sqrt by v_rsq_f64 + two Newton steps (the IEEE sqrt and divide sequences are
-                // ~80 dependent instructions per column of this 16-long serial chain)
-                const double ap = akk > 0.0 ? akk : 1.0;
-                double rp = __builtin_amdgcn_rsq(ap);
-                rp = rp * fma(-0.5 * ap * rp, rp, 1.5);
-                rp = rp * fma(-0.5 * ap * rp, rp, 1.5);
-                double piv = ap * rp;
-                piv = fma(fma(-piv, piv, ap), 0.5 * rp, piv);   // one correction step of sqrt itself
-                rdiag[k] = rp;
-                double lk = r > k ? row[k] * rp : 0.0;
-                row[k] = r == k ? piv : lk;
+        for (int k = 0; k < 16; ++k) {
+            double akk = readlane_f64(row[k], k);
+            if (!(akk > 0.0) && bad == 0 && o + k < D) bad = o + k + 1;
+            // 1/sqrt by v_rsq_f64 + two Newton steps (the IEEE sqrt and divide sequences are
+            // ~80 dependent instructions per column of this 16-long serial chain)
+            const double ap = akk > 0.0 ? akk : 1.0;
+            double rp = __builtin_amdgcn_rsq(ap);
+            rp = rp * fma(-0.5 * ap * rp, rp, 1.5);
+            rp = rp * fma(-0.5 * ap * rp, rp, 1.5);
+            double piv = ap * rp;
+            piv = fma(fma(-piv, piv, ap), 0.5 * rp, piv);   // one correction step of sqrt itself
+            rdiag[k] = rp;
+            double lk = r > k ? row[k] * rp : 0.0;
+            row[k] = r == k ? piv : lk;
 #pragma unroll
-                for (int j = k + 1; j < 16; ++j) {
-                    double ljk = readlane_f64(lk, j);
-                    row[j] = fma(-lk, ljk, row[j]);
-                }
+            for (int j = k + 1; j < 16; ++j) {
+                double ljk = readlane_f64(lk, j);
+                row[j] = fma(-lk, ljk, row[j]);
             }
-            if (lane < 16) {
-#pragma unroll
-                for (int cc = 0; cc < 16; ++cc) a[(o + r) * kSmallLd + o + cc] = cc <= r ? row[cc] : 0.0;
-            }
-            if (bad && lane == 0) s_bad = bad;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) rdiag[k] = vt_rcp(readlane_f64(row[k], k));
         }
-        // inverse: lane c holds column c of L_JJ^{-1}:  x_i = (delta_ic - sum_{m<i} L[i][m] x_m) / L[i][i]
-        const int c = r;
+        if (lane < 16) {
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) a[(o + r) * kSmallLd + o + cc] = cc <= r ? row[cc] : 0.0;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) rdiag_s[o + k] = rdiag[k];
+        }
+        if (bad && lane == 0) s_bad = bad;
+    };
+    // inverse of the factored block J (any wave): lane c holds column c of L_JJ^{-1},
+    //   x_i = (delta_ic - sum_{m<i} L[i][m] x_m) / L[i][i];  L[i][m] are uniform (broadcast) LDS reads
+    auto diag_invert = [&](int J) __attribute__((always_inline)) {
+        const int o = 16 * J;
+        const int c = lane & 15;
         double x[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             double sacc = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-            for (int m = 0; m < i; ++m) sacc = fma(-readlane_f64(row[m], i), x[m], sacc);
-            x[i] = i < c ? 0.0 : sacc * rdiag[i];
+            for (int m = 0; m < i; ++m) sacc = fma(-a[(o + i) * kSmallLd + o + m], x[m], sacc);
+            x[i] = i < c ? 0.0 : sacc * rdiag_s[o + i];
         }
         if (lane < 16) {
 #pragma unroll
@@ -137,47 +144,54 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(const double* Ain, int
     };
 
     if (!do_factor) {
-        // A already holds L: only the inverted diagonal blocks are needed (one per wave at a time)
-        for (int J = wave; J < NB; J += 4) diag_block(J);
+        // A already holds L: only the inverted diagonal blocks are needed
+        if (tid < NP) rdiag_s[tid] = vt_rcp(a[tid * kSmallLd + tid]);
+        __syncthreads();
+        for (int J = wave; J < NB; J += 4) diag_invert(J);
     } else {
-        if (wave == 0 && !(VT_PABL & 1)) diag_block(0);
+        if (wave == 0 && !(VT_PABL & 1)) diag_factor(0);
         __syncthreads();
         for (int J = 0; J < NB && !s_bad; ++J) {
             const int o = 16 * J;
             if (J + 1 == NB) break;
-            // ---- (b) panel: row R of the blocks below:  L[R][o..o+15] = A[R][o..] * Linv^T ----
+            // ---- (b) panel: row R of the blocks below:  t L_JJ^T = A[R][o..o+15]  by substitution ----
             const int R = o + 16 + tid;
             if (R < NP && !(VT_PABL & 2)) {
-                double t[16], u[16];
+                double t[16];
 #pragma unroll
                 for (int m = 0; m < 16; ++m) t[m] = a[R * kSmallLd + o + m];
 #pragma unroll
-                for (int cc = 0; cc < 16; ++cc) {
-                    double sacc = 0.0;
+                for (int m = 0; m < 16; ++m) {
+                    t[m] *= rdiag_s[o + m];
 #pragma unroll
-                    for (int m = 0; m <= cc; ++m) sacc = fma(t[m], linv[(J * 16 + cc) * 17 + m], sacc);
-                    u[cc] = sacc;
+                    for (int cc = m + 1; cc < 16; ++cc) t[cc] = fma(-t[m], a[(o + cc) * kSmallLd + o + m], t[cc]);
                 }
 #pragma unroll
-                for (int cc = 0; cc < 16; ++cc) a[R * kSmallLd + o + cc] = u[cc];
+                for (int cc = 0; cc < 16; ++cc) a[R * kSmallLd + o + cc] = t[cc];
             }
             __syncthreads();
             // ---- (c) trailing update with look-ahead: wave 0 updates the next diagonal block first and
-            //      factors it while waves 1..3 update the rest of the trailing matrix --------------------
+            //      factors it while waves 1..3 update the rest of the trailing matrix and wave 1 inverts
+            //      the block the panel was just solved against (needed by the TRSM pack only) --------------
             const int nb = NB - J - 1;
             const int nt = nb * (nb + 1) / 2;
             if (wave == 0) {
                 if (!(VT_PABL & 4)) trailing_tile(o, 0, 0);
-                if (!(VT_PABL & 1)) diag_block(J + 1);
-            } else if (!(VT_PABL & 4)) {
-                for (int t = wave; t < nt; t += 3) {    // tiles 1..nt-1 over waves 1..3
-                    int bi = 0;
-                    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-                    trailing_tile(o, bi, t - bi * (bi + 1) / 2);
+                if (!(VT_PABL & 1)) diag_factor(J + 1);
+            } else {
+                if (!(VT_PABL & 4)) {
+                    for (int t = wave; t < nt; t += 3) {    // tiles 1..nt-1 over waves 1..3
+                        int bi = 0;
+                        while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+                        trailing_tile(o, bi, t - bi * (bi + 1) / 2);
+                    }
                 }
+                if (wave == 1 && pack != nullptr) diag_invert(J);
             }
             __syncthreads();
         }
+        // the last diagonal block was factored by the final look-ahead (or is block 0 when NB = 1)
+        if (pack != nullptr && !s_bad && wave == 0) diag_invert(NB - 1);
     }
     __syncthreads();
     const int bad = s_bad;
