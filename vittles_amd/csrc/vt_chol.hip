@@ -44,20 +44,21 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(const double* Ain, int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NB = (D + 15) >> 4, NP = NB * 16, NBT = NB * (NB + 1) / 2;
     if (tid == 0) s_bad = 0;
-    // zero-padded lower triangle -> LDS (identity on the padding diagonal); 128 threads per row, 8 rows'
-    // loads in flight per thread (unconditional, clamped: a predicated load drains vmcnt every iteration)
+    // zero-padded lower triangle -> LDS (identity on the padding diagonal); 128 threads per row, 32 rows'
+    // loads in flight per thread (unconditional, clamped: a predicated load drains vmcnt every iteration),
+    // so the whole matrix arrives in at most two memory latencies
     {
         const int j = tid & 127;
         const int jc = j < D ? j : D - 1;
-        for (int i0 = tid >> 7; i0 < NP; i0 += 16) {
-            double v[8];
+        for (int i0 = tid >> 7; i0 < NP; i0 += 64) {
+            double v[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 32; ++u) {
                 const int i = i0 + 2 * u;
                 v[u] = Ain[(int64_t)(i < D ? i : D - 1) * ldin + jc];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 32; ++u) {
                 const int i = i0 + 2 * u;
                 if (i < NP && j < NP) a[i * kSmallLd + j] = (i < D && j <= i) ? v[u] : ((i >= D && j == i) ? 1.0 : 0.0);
             }
