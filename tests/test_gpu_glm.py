@@ -30,7 +30,7 @@ def _problem(N, D, family, seed, prior=1.0, with_offset=False):
                                  (2000, 100), (513, 128), (1001, 97), (300, 113),
                                  # N >= 4096: the LDS-tile kernel (48-row tiles, ragged last tile, NB = 4..7)
                                  (4096, 50), (4099, 64), (5003, 77), (4801, 96), (20001, 100), (12289, 112),
-                                 (4100, 99), (5000, 128)])
+                                 (4100, 99), (5000, 128), (4500, 113), (6001, 127), (4096, 120)])
 @pytest.mark.parametrize("family", ["logistic", "poisson", "gaussian"])
 def test_fused_hessian_grad(N, D, family, relerr):
     from oracle import glm

@@ -11,4 +11,5 @@ for name, cs in acc.items():
         continue
     print(name)
     for c, v in sorted(cs.items()):
-        print("   %-32s n=%-4d mean=%.4g" % (c, len(v), sum(v) / len(v)))
+        # max = the full-size dispatches when small launches of the same kernel (set-up solves) dilute the mean
+        print("   %-32s n=%-4d mean=%.4g max=%.4g" % (c, len(v), sum(v) / len(v), max(v)))

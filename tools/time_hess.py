@@ -12,10 +12,10 @@ for fam in ("gaussian", "logistic"):
     def f():
         obj._cache_key = None
         return obj.fused(theta, w)
-    for _ in range(3): f()
+    for _ in range(100): f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(20): f()
+    for _ in range(200): f()
     e1.record(); torch.cuda.synchronize()
-    print(os.environ.get("VITTLES_HIP_LIB", "default")[-22:], fam, "%.3f ms" % (e0.elapsed_time(e1) / 20))
+    print(os.environ.get("VITTLES_HIP_LIB", "default")[-22:], fam, "%.3f ms" % (e0.elapsed_time(e1) / 200))

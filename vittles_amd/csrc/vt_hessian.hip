@@ -284,6 +284,13 @@ __host__ __device__ constexpr int blk_ord(int NB, int i, int j) { return (NB * (
 __host__ __device__ constexpr int blk_owner(int NB, int NQ, int i, int j) {
     return blk_ord(NB, i, j) * NQ / (NB * (NB + 1) / 2);
 }
+// does quarter Q own a block in block row or block column b?
+__host__ __device__ constexpr bool blk_needed(int NB, int NQ, int Q, int b) {
+    for (int i = 0; i < NB; ++i)
+        for (int j = 0; j <= i; ++j)
+            if (blk_owner(NB, NQ, i, j) == Q && (i == b || j == b)) return true;
+    return false;
+}
 __host__ __device__ constexpr int own_first(int NB, int NQ, int Q) { return (Q * (NB * (NB + 1) / 2) + NQ - 1) / NQ; }
 
 template <int NB>
@@ -351,17 +358,36 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
             }
         }
     };
-    auto mfma_part = [&](int buf, int kfirst, auto count) {
-        constexpr int CNT = decltype(count)::value;
+    // k-steps [kfirst, kfirst + cnt) of the tile in `buf`.  ONE code path for all three roles, a real
+    // loop with a wave-uniform trip count: when every role had its own unrolled copy, hipcc gave the
+    // accumulators different registers on each path and moved all of them back (28 v_mov_b64 behind an
+    // s_nop 15) every period.
+    auto mfma_part = [&](int buf, int kfirst, int cnt) {
         if (!(VT_ABL & 1)) {
-            const double* tb = lds + LY::kTile + buf * (TR * RS) + (q + 4 * kfirst) * RS + c;
-            const double* db = lds + LY::kD + buf * TR + q + 4 * kfirst;
+            // The operand reads are inline asm: as compiler-visible LDS loads they make hipcc wait for the
+            // FETCH wave's own LDS-DMA (vmcnt(0): it cannot tell the tile buffers apart) once the loop
+            // hides the buffer offsets.  (Tried on top of this: two operand sets in rotation, the reads of
+            // k-step m+1 in flight under the MFMAs of m -- no gain, the other two waves of the SIMD
+            // already cover the LDS latency.)
+            unsigned ta = (unsigned)(uintptr_t)(vt_ldsptr)(lds + LY::kTile + buf * (TR * RS) + (q + 4 * kfirst) * RS + c);
+            unsigned da = (unsigned)(uintptr_t)(vt_ldsptr)(lds + LY::kD + buf * TR + q + 4 * kfirst);
+#pragma nounroll
+            for (int m = 0; m < cnt; ++m) {
+                double xa[8];
+                double dq;
+                asm volatile("ds_read_b64 %0, %1" : "=v"(dq) : "v"(da));
 #pragma unroll
-            for (int m = 0; m < CNT; ++m) {
-                double xa[NB];
-#pragma unroll
-                for (int b = 0; b < NB; ++b) xa[b] = tb[4 * m * RS + 16 * b];
-                const double dq = db[4 * m];
+                for (int b = 0; b < NB; ++b) {
+                    if (blk_needed(NB, NQ, Q, b))   // column blocks this quarter's products touch
+                        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xa[b]) : "v"(ta), "n"(128 * b));
+                    else
+                        xa[b] = 0.0;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dq), "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]));
+                if constexpr (NB > 4) asm volatile("" : "+v"(xa[4]));
+                if constexpr (NB > 5) asm volatile("" : "+v"(xa[5]));
+                if constexpr (NB > 6) asm volatile("" : "+v"(xa[6]));
+                if constexpr (NB > 7) asm volatile("" : "+v"(xa[7]));
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     const double bj = dq * xa[j];
@@ -370,8 +396,8 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
                         if (blk_owner(NB, NQ, i, j) == Q)
                             acc[blk_ord(NB, i, j) - FIRST] = mfma_f64(xa[i], bj, acc[blk_ord(NB, i, j) - FIRST]);
                 }
-                // one k-step's operands at a time: deeper operand prefetch (tried: double-buffered
-                // xa) makes hipcc spill the accumulators around the role branches
+                ta += 4 * RS * 8;
+                da += 4 * 8;
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -449,18 +475,23 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
     for (int64_t p = -1; p < mine; ++p) {
         const int b1 = b0 == 2 ? 0 : b0 + 1;           // buffer of tile p+1
         const int b2 = b1 == 2 ? 0 : b1 + 1;           // buffer of tile p+2
-        if (role == 1 && !(VT_ABL & 8)) {
-            dma(p + 2, b2);
-            load_scal(p + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if (p >= 0) mfma_part(b0, KD, std::integral_constant<int, KO>());
-        } else if (role == 0 && !(VT_ABL & 4)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my own DMA of tile p+1 (issued a period ago)
-            link(p + 1, b1);
-            if (p >= 0) mfma_part(b0, 0, std::integral_constant<int, KD>());
-        } else {
-            if (p >= 0) mfma_part(b0, role == 2 ? KD + KO : (role == 1 ? KD : 0), std::integral_constant<int, KO>());
+        int kfirst = KD + KO, cnt = KO;                 // PLAIN
+        if (role == 1) {                                 // FETCH
+            kfirst = KD;
+            if (!(VT_ABL & 8)) {
+                dma(p + 2, b2);
+                load_scal(p + 2);
+            }
+        } else if (role == 0) {                          // LINK
+            kfirst = 0;
+            cnt = KD;
+            if (!(VT_ABL & 4)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my own DMA of tile p+1 (issued a period ago)
+                link(p + 1, b1);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (p >= 0) mfma_part(b0, kfirst, cnt);
         vt_lds_barrier();
         b0 = b1;
         role = role == 0 ? 2 : role - 1;               // FETCH -> LINK -> PLAIN -> FETCH
@@ -692,7 +723,7 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
     }
     const int NB = (D + 15) / 16;
     const int L = slab_len(NB);
-    const bool tiled = N >= kTileMinRows && NB >= 4 && NB <= 7 && (ldx % 2 == 0) && ((uintptr_t)X % 16 == 0) &&
+    const bool tiled = N >= kTileMinRows && NB >= 4 && NB <= 8 && (ldx % 2 == 0) && ((uintptr_t)X % 16 == 0) &&
                        !getenv("VT_HESS_NO_TILE");
     const int64_t ntiles = (N + tile_rows(NB) - 1) / tile_rows(NB);
     const int grid = tiled ? (int)std::min<int64_t>(ntiles, num_cu()) : hess_grid(N);
