@@ -82,3 +82,19 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_next_rows_host_checks_need_no_gpu():
+    """Host logic of the SURVEY.md section 8(f) rows that runs before any kernel."""
+    import vittles_amd as va
+    from vittles_amd import _lib
+    lib = _lib.load()
+    assert lib.vt_gemm_tn_workspace_bytes(64, 100) > 0
+    assert lib.vt_gemm_tn_workspace_bytes(64, 100) % (128 * 128 * 8) == 0     # whole 128 x 128 slabs
+    assert lib.vt_gemm_tn_workspace_bytes(8193, 10) == 0 and lib.vt_gemm_tn_workspace_bytes(0, 10) == 0
+    with pytest.raises(TypeError):
+        va.optim.newton_glm(lambda t, w: 0.0, np.ones(3))
+    with pytest.raises(NotImplementedError):                      # arbitrary callables need autograd
+        va.ParametricSensitivityTaylorExpansion.optimization_objective(
+            lambda t, w: 0.0, np.zeros(2), np.zeros(3), order=2)
+    assert isinstance(va.__version__, str)
