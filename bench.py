@@ -288,7 +288,7 @@ def main():
                      "TFLOPs_full_square": 2.0 * N * D * D / (ms_hess * 1e-3) / 1e12,
                      "hbm_GBs": (8.0 * N * D + 24.0 * N) / (ms_hess * 1e-3) / 1e9},
         }
-        if not args.no_hvp:
+        if not args.no_hvp and world == 1:   # side measurements run at N=1 only: no rank waits on rank 0
             result["hvp"] = hvp_side_measurement(torch, device, args.hvp_rows, args.hvp_dim)
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 at N=1 only
             n_s = min(args.cpu_rows, N)
