@@ -39,6 +39,8 @@ def _worker(rank, world, port, N, D, q):
         jac_local = glm.cross_hessian("logistic", Xs, ys, theta, ws)
         S_local = -scipy.linalg.cho_solve(scipy.linalg.cho_factor(H.numpy()), jac_local)
         H_full, _, S_full = glm.sensitivity("logistic", X, y, theta, w, prior=1.0)
+        # host-side control flow takes rank 0's numbers on every rank
+        assert sharding.agree_scalars([float(rank) + 0.5, 2.0], dist.group.WORLD, None) == [0.5, 2.0]
         q.put((rank, float(np.abs(H.numpy() - H_full).max() / np.abs(H_full).max()),
                float(np.abs(S_local - S_full[:, a:b]).max() / np.abs(S_full).max()),
                float(np.linalg.norm(g.numpy())), (a, b)))

@@ -10,7 +10,7 @@ all-reduced exactly as on the sensitivity path, so every rank takes identical st
 """
 import torch
 
-from . import device as dev
+from . import device as dev, sharding
 from .linalg import DeviceCholesky
 from .objectives import WeightedGLMObjective
 
@@ -38,7 +38,12 @@ def newton_glm(objective, hyper_par, opt_par_init=None, max_iter=50, grad_tol=1e
         theta = dev.to_device(opt_par_init, objective.device).clone().contiguous()
         if theta.shape != (D,):
             raise ValueError('opt_par_init must have shape (%d,)' % D)
-    value = objective.value(theta, w)
+    group = objective.process_group
+
+    def agree(*vals):           # every rank branches on rank 0's numbers (see sharding.agree_scalars)
+        return sharding.agree_scalars(vals, group, objective.device)
+
+    (value,) = agree(objective.value(theta, w))
     halvings_total = 0
     converged = False
     gnorm = float('inf')
@@ -46,31 +51,33 @@ def newton_glm(objective, hyper_par, opt_par_init=None, max_iter=50, grad_tol=1e
     for it in range(1, max_iter + 1):
         out = objective.fused(theta, w)                     # K0 + K1 + K3 (+ all-reduce)
         g, H = out["g"], out["H"]
-        gnorm = float(torch.linalg.vector_norm(g).item())
+        (gnorm,) = agree(float(torch.linalg.vector_norm(g).item()))
         if gnorm <= grad_tol:
             converged = True
             it -= 1
             break
         step = DeviceCholesky.factor(H, pack=True).solve(g)  # K4 + K5; LinAlgError if H is not PD
-        slope = float(torch.dot(g, step).item())            # > 0 for PD H
+        slope, step_norm, theta_norm = agree(float(torch.dot(g, step).item()),            # slope > 0 for PD H
+                                             float(torch.linalg.vector_norm(step).item()),
+                                             float(torch.linalg.vector_norm(theta).item()))
         # objective values carry rounding noise of a few ulps of |f|: once the predicted decrease
         # is below it the value test says nothing, and the full Newton step is taken
         noise = 64.0 * 2.2e-16 * max(1.0, abs(value))
         t = 1.0
         for _ in range(max_halvings + 1):
             cand = theta - t * step
-            cand_value = objective.value(cand, w)
+            (cand_value,) = agree(objective.value(cand, w))
             if cand_value == cand_value and cand_value <= value - armijo * t * slope + noise:
                 break
             t *= 0.5
             halvings_total += 1
         else:
             break                                            # no decrease along the Newton direction
-        snorm = t * float(torch.linalg.vector_norm(step).item())
+        snorm = t * step_norm
         theta, value = cand, cand_value
-        if snorm <= step_tol * max(1.0, float(torch.linalg.vector_norm(theta).item())):
+        if snorm <= step_tol * max(1.0, theta_norm):
             out = objective.fused(theta, w)
-            gnorm = float(torch.linalg.vector_norm(out["g"]).item())
+            (gnorm,) = agree(float(torch.linalg.vector_norm(out["g"]).item()))
             converged = gnorm <= max(grad_tol, 1e-6)
             break
     info = dict(iterations=it, grad_norm=gnorm, value=value, converged=converged, halvings=halvings_total)

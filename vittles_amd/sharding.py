@@ -65,3 +65,19 @@ def all_reduce_sum(tensors, group):
             t.copy_(flat[off:off + n].view_as(t))
             off += n
     return tensors
+
+
+def agree_scalars(values, group, device):
+    """Return rank 0's copy of a list of Python floats on every rank of ``group``.
+
+    Host-side control flow that depends on reduced quantities (an optimiser's stopping and
+    line-search tests) must take the same branch on every rank, or the ranks' collectives stop
+    matching.  All-reduce results are normally bit-identical across ranks; this makes the
+    agreement explicit at the cost of one tiny broadcast."""
+    if group is None:
+        return list(values)
+    import torch.distributed as dist
+    staged = dist.get_backend(group) != "nccl"
+    t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if staged else device)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0), group=group)
+    return [float(v) for v in t.tolist()]
