@@ -187,3 +187,28 @@ def test_vt_potrs_generic_kernel_direct(D, K, relerr):
     x = torch.tensor(B, device="cuda").contiguous()
     _lib.check(_lib.load().vt_potrs(chol.L.data_ptr(), D, D, x.data_ptr(), K, 1, K, dev.stream_ptr()), "vt_potrs")
     assert relerr(x.cpu().numpy(), np.linalg.solve(H, B)) < 1e-9
+
+
+@pytest.mark.parametrize("D", [5, 100, 200])
+def test_empty_data_set(D, relerr):
+    """N = 0 rows (an empty hyper-parameter vector): H = prior, g = prior .* theta, S has shape (D, 0),
+    predictions return theta-hat -- what autograd + SciPy give the reference for an empty sum."""
+    torch = _torch()
+    import vittles_amd as va
+    from vittles_amd import rows
+    X = np.zeros((0, D)); y = np.zeros(0); w = np.zeros(0)
+    theta = 0.1 * np.arange(D)
+    prior = np.linspace(1.0, 2.0, D)
+    obj = va.WeightedGLMObjective(X, y, family="logistic", prior=prior)
+    out = obj.fused(theta, w)
+    assert relerr(out["H"].cpu().numpy(), np.diag(prior)) == 0.0
+    assert relerr(out["g"].cpu().numpy(), prior * theta) < 1e-15
+    assert abs(obj(theta, w) - 0.5 * np.sum(prior * theta ** 2)) < 1e-12
+    la = va.HyperparameterSensitivityLinearApproximation(obj, theta, w)
+    assert la.get_dopt_dhyper().shape == (D, 0)
+    assert relerr(la.predict_opt_par_from_hyper_par(w), theta) == 0.0
+    z = lambda *s: torch.zeros(s, dtype=torch.float64, device="cuda")
+    bias = torch.arange(4, dtype=torch.float64, device="cuda")
+    assert np.array_equal(rows.gemm_tn(z(0, 3), z(0, 4), bias=bias).cpu().numpy(), np.tile(np.arange(4.0), (3, 1)))
+    th, info = va.optim.newton_glm(obj, w)
+    assert info["converged"] and np.abs(th).max() < 1e-12          # minimiser of the prior alone

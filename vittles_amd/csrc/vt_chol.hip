@@ -644,9 +644,10 @@ extern "C" int vt_potrf_pack_from(const double* H, int ldh, double* L, int ldl, 
 
 extern "C" int vt_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale,
                             double alpha, int64_t N, double* Out, int64_t ldo, void* stream) {
-    if (!pack || !B || !Out || D < 1 || ldb < D || ldo < D || N < 0) return VT_ERR_BAD_ARG;
+    if (!pack || D < 1 || ldb < D || ldo < D || N < 0) return VT_ERR_BAD_ARG;
     if (D > kLargeDMax) return VT_ERR_UNSUPPORTED;
     if (N == 0) return VT_OK;
+    if (!B || !Out) return VT_ERR_BAD_ARG;
     if (D > VT_SMALL_D_MAX)
         return vt_large_trsm_rows(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, (hipStream_t)stream);
     return vt_trsm_rows_mode(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, 0, (hipStream_t)stream);

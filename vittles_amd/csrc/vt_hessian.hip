@@ -705,7 +705,9 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
                               const double* y, const double* w, const double* offset, double scale,
                               const double* prior, int64_t N, int D, double* H, int ldh, double* g,
                               double* r, double* d, void* ws, size_t ws_bytes, void* stream) {
-    if (!X || !theta || !y || !w || !H || N < 0 || D < 1 || ldx < D || ldh < D) return VT_ERR_BAD_ARG;
+    // N == 0 (no rows: H = prior, g = prior .* theta) needs no row data
+    if (!theta || !H || N < 0 || D < 1 || ldx < D || ldh < D) return VT_ERR_BAD_ARG;
+    if (N > 0 && (!X || !y || !w)) return VT_ERR_BAD_ARG;
     if (family < 0 || family > 2) return VT_ERR_BAD_ARG;
     if (!ws || ws_bytes < vt_glm_hessian_workspace_bytes(N, D)) return VT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -732,6 +734,11 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
     double* wave_part = part2 + (size_t)kStage2 * L;
     double* sink = wave_part + (size_t)num_cu() * 4 * (NB * (NB + 1) / 2) * 256;
 
+    if (N == 0) {   // nothing to stream: the finalize kernel sums zero slabs and adds the prior
+        hipLaunchKernelGGL(k_hess_finalize, dim3((L + 15) / 16), dim3(256), 0, st, (const double*)part, L, 0, NB, D,
+                           prior, theta, H, ldh, g);
+        return vt_launch_status();
+    }
     static const int ablate = getenv("VT_HESS_ABLATE") ? atoi(getenv("VT_HESS_ABLATE")) : 0;
     HessArgs a{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, wave_part, sink, ablate};
     if (tiled) {

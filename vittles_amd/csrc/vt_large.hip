@@ -644,7 +644,9 @@ int vt_large_syrk(const double* X, int64_t ldx, const double* d, int64_t N, int 
     int64_t nsteps = (N + 3) / 4;
     if (ks > nsteps) ks = (int)std::max<int64_t>(1, nsteps);
     SyrkArgs a{X, ldx, d, N, D, nt, ks, (double*)ws, nullptr, 0, 0, 0};
-    if (ldx % 2 == 0 && (uintptr_t)X % 16 == 0 && !getenv("VT_LARGE_NO_LDS")) {
+    if (N == 0) {
+        ks = 0;   // no rows: the reduce below sums zero slabs and adds the prior
+    } else if (ldx % 2 == 0 && (uintptr_t)X % 16 == 0 && !getenv("VT_LARGE_NO_LDS")) {
         const size_t shmem = (size_t)kStages * 2 * kKC * (kT + 16) * sizeof(double);   // 108 KB
         static bool attr_set = false;
         if (!attr_set) {
@@ -679,7 +681,8 @@ extern "C" size_t vt_gemm_tn_workspace_bytes(int Da, int Db) {
 extern "C" int vt_gemm_tn(const double* A, int64_t lda, int Da, const double* B, int64_t ldb, int Db,
                           const double* rowscale, int64_t N, double alpha, const double* bias, double* C,
                           int64_t ldc, void* ws, size_t ws_bytes, void* stream) {
-    if (!A || !B || !C || N < 0 || Da < 1 || Db < 1 || lda < Da || ldb < Db || ldc < Db) return VT_ERR_BAD_ARG;
+    if (!C || N < 0 || Da < 1 || Db < 1 || lda < Da || ldb < Db || ldc < Db) return VT_ERR_BAD_ARG;
+    if (N > 0 && (!A || !B)) return VT_ERR_BAD_ARG;
     if (Da > VT_DENSE_D_MAX || Db > VT_DENSE_D_MAX) return VT_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < vt_gemm_tn_workspace_bytes(Da, Db)) return VT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -688,7 +691,9 @@ extern "C" int vt_gemm_tn(const double* A, int64_t lda, int Da, const double* B,
     const int64_t nsteps = (N + kKC - 1) / kKC;
     if (ks > nsteps) ks = (int)std::max<int64_t>(1, nsteps);
     SyrkArgs a{A, lda, rowscale, N, Da, nta, ks, (double*)ws, B, ldb, Db, ntb};
-    if (lda % 2 == 0 && ldb % 2 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0 && !getenv("VT_LARGE_NO_LDS")) {
+    if (N == 0) {
+        ks = 0;   // no rows: C = bias
+    } else if (lda % 2 == 0 && ldb % 2 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0 && !getenv("VT_LARGE_NO_LDS")) {
         const size_t shmem = (size_t)kStages * 2 * kKC * (kT + 16) * sizeof(double);   // 108 KB
         static bool attr_set = false;
         if (!attr_set) {

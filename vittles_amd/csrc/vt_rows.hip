@@ -525,7 +525,7 @@ extern "C" size_t vt_rows_workspace_bytes(int D) {
 }
 
 #define VT_ROWS_PROLOGUE                                                                  \
-    if (!X || N < 0 || D < 1 || ldx < D) return VT_ERR_BAD_ARG;                           \
+    if ((!X && N > 0) || N < 0 || D < 1 || ldx < D) return VT_ERR_BAD_ARG;                \
     if (!ws || ws_bytes < vt_rows_workspace_bytes(D)) return VT_ERR_WORKSPACE;            \
     hipStream_t st = (hipStream_t)stream;
 
@@ -534,8 +534,8 @@ extern "C" int vt_glm_link(int family, const double* X, int64_t ldx, const doubl
                            double* z_out, double* r_out, double* d_out, void* ws, size_t ws_bytes,
                            void* stream) {
     VT_ROWS_PROLOGUE
-    if (!theta || !y || !w) return VT_ERR_BAD_ARG;
     if (N == 0) return VT_OK;
+    if (!theta || !y || !w) return VT_ERR_BAD_ARG;
     RowArgs a{X, ldx, N, D, theta, y, w, offset, nullptr, scale, family, z_out, r_out, d_out, (double*)ws};
     int P = run_rows<OP_LINK>(a, st);
     return P < 0 ? P : VT_OK;
@@ -546,7 +546,7 @@ extern "C" int vt_glm_grad(int family, const double* X, int64_t ldx, const doubl
                            int64_t N, int D, double* g_out, double* r_out, double* d_out, void* ws,
                            size_t ws_bytes, void* stream) {
     VT_ROWS_PROLOGUE
-    if (!theta || !y || !w || !g_out) return VT_ERR_BAD_ARG;
+    if (!theta || !g_out || (N > 0 && (!y || !w))) return VT_ERR_BAD_ARG;
     int P = 0;
     if (N > 0) {
         RowArgs a{X, ldx, N, D, theta, y, w, offset, nullptr, scale, family, nullptr, r_out, d_out, (double*)ws};
@@ -560,7 +560,7 @@ extern "C" int vt_glm_hvp(const double* X, int64_t ldx, const double* d, const d
                           double prior_scalar, const double* v, int64_t N, int D, double* out, void* ws,
                           size_t ws_bytes, void* stream) {
     VT_ROWS_PROLOGUE
-    if (!d || !v || !out) return VT_ERR_BAD_ARG;
+    if (!v || !out || (N > 0 && !d)) return VT_ERR_BAD_ARG;
     int P = 0;
     if (N > 0) {
         RowArgs a{X, ldx, N, D, v, nullptr, nullptr, nullptr, d, 1.0, 0, nullptr, nullptr, nullptr, (double*)ws};
@@ -574,7 +574,7 @@ extern "C" int vt_glm_hvp(const double* X, int64_t ldx, const double* d, const d
 extern "C" int vt_gemv_t(const double* X, int64_t ldx, const double* u, int64_t N, int D, double* out,
                          void* ws, size_t ws_bytes, void* stream) {
     VT_ROWS_PROLOGUE
-    if (!u || !out) return VT_ERR_BAD_ARG;
+    if (!out || (N > 0 && !u)) return VT_ERR_BAD_ARG;
     int P = 0;
     if (N > 0) {
         RowArgs a{X, ldx, N, D, nullptr, nullptr, nullptr, nullptr, u, 1.0, 0, nullptr, nullptr, nullptr, (double*)ws};
@@ -587,7 +587,7 @@ extern "C" int vt_gemv_t(const double* X, int64_t ldx, const double* u, int64_t 
 extern "C" int vt_gemv_t2(const double* X, int64_t ldx, const double* u1, const double* u2, int64_t N, int D,
                           double* out, void* ws, size_t ws_bytes, void* stream) {
     VT_ROWS_PROLOGUE
-    if (!u1 || !u2 || !out) return VT_ERR_BAD_ARG;
+    if (!out || (N > 0 && (!u1 || !u2))) return VT_ERR_BAD_ARG;
     int P = 0;
     if (N > 0) {
         RowArgs a{X, ldx, N, D, nullptr, u2, nullptr, nullptr, u1, 1.0, 0, nullptr, nullptr, nullptr, (double*)ws};
@@ -601,7 +601,7 @@ extern "C" int vt_glm_taylor2_rhs(int family, const double* X, int64_t ldx, cons
                                   const double* dw, double scale, const double* u, int64_t N, int D, double* out,
                                   void* ws, size_t ws_bytes, void* stream) {
     VT_ROWS_PROLOGUE
-    if (!z || !w || !dw || !u || !out) return VT_ERR_BAD_ARG;
+    if (!u || !out || (N > 0 && (!z || !w || !dw))) return VT_ERR_BAD_ARG;
     int P = 0;
     if (N > 0) {
         RowArgs a{X, ldx, N, D, u, z, w, nullptr, dw, scale, family, nullptr, nullptr, nullptr, (double*)ws};
@@ -614,8 +614,8 @@ extern "C" int vt_glm_taylor2_rhs(int family, const double* X, int64_t ldx, cons
 extern "C" int vt_gemv(const double* X, int64_t ldx, const double* v, int64_t N, int D, double* out,
                        void* ws, size_t ws_bytes, void* stream) {
     VT_ROWS_PROLOGUE
-    if (!v || !out) return VT_ERR_BAD_ARG;
     if (N == 0) return VT_OK;
+    if (!v || !out) return VT_ERR_BAD_ARG;
     RowArgs a{X, ldx, N, D, v, nullptr, nullptr, nullptr, nullptr, 1.0, 0, out, nullptr, nullptr, (double*)ws};
     int P = run_rows<OP_GEMV>(a, st);
     return P < 0 ? P : VT_OK;
@@ -625,7 +625,7 @@ extern "C" int vt_glm_value(int family, const double* X, int64_t ldx, const doub
                             const double* w, const double* offset, double scale, int64_t N, int D,
                             double* value_out, void* ws, size_t ws_bytes, void* stream) {
     VT_ROWS_PROLOGUE
-    if (!theta || !y || !w || !value_out) return VT_ERR_BAD_ARG;
+    if (!theta || !value_out || (N > 0 && (!y || !w))) return VT_ERR_BAD_ARG;
     int P = 0;
     if (N > 0) {
         RowArgs a{X, ldx, N, D, theta, y, w, offset, nullptr, scale, family, nullptr, nullptr, nullptr, (double*)ws};

@@ -38,6 +38,13 @@ def like_input(result, template):
     return result.cpu().numpy()
 
 
+def ld(t):
+    """Leading dimension (row stride in elements) of a row-major 2-D tensor for the C-ABI.  torch
+    reports arbitrary strides (0, 1) for tensors with fewer than two rows; any value >= the row
+    length is right for them."""
+    return t.stride(0) if t.shape[0] > 1 else max(int(t.shape[1]), 1)
+
+
 def ptr(t):
     return 0 if t is None else t.data_ptr()
 

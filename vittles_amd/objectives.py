@@ -66,7 +66,7 @@ class WeightedGLMObjective(RegisteredObjective):
         self.X = dev.to_device(X, device)
         if self.X.ndim != 2:
             raise ValueError("X must be (N, D)")
-        if self.X.stride(1) != 1:
+        if self.X.shape[0] > 0 and self.X.stride(1) != 1:
             self.X = self.X.contiguous()
         self.N, self.D = self.X.shape
         self.device = self.X.device
@@ -122,7 +122,7 @@ class WeightedGLMObjective(RegisteredObjective):
         d = torch.empty(self.N, dtype=torch.float64, device=self.device)
         prior = self.prior if self._rank() == 0 else None
         _lib.check(lib.vt_glm_hessian(
-            _lib.FAMILY[self.family], self.X.data_ptr(), self.X.stride(0), theta.data_ptr(),
+            _lib.FAMILY[self.family], self.X.data_ptr(), dev.ld(self.X), theta.data_ptr(),
             self.y.data_ptr(), w.data_ptr(), dev.ptr(self.offset), self.scale, dev.ptr(prior),
             self.N, self.D, H.data_ptr(), self.D, g.data_ptr(), r.data_ptr(), d.data_ptr(),
             self._ws.data_ptr(), self._ws.numel() * 8, dev.stream_ptr()), "vt_glm_hessian")

@@ -18,7 +18,7 @@ def _workspace(D, device):
 
 
 def _rowmajor(A):
-    return A if A.stride(1) == 1 else A.contiguous()
+    return A if (A.stride(1) == 1 or A.shape[0] == 0) else A.contiguous()
 
 
 def gemv_t(A, u):
@@ -29,7 +29,7 @@ def gemv_t(A, u):
     u = u.contiguous()
     out = torch.empty(D, dtype=torch.float64, device=A.device)
     ws = _workspace(D, A.device)
-    _lib.check(lib.vt_gemv_t(A.data_ptr(), A.stride(0), u.data_ptr(), N, D, out.data_ptr(),
+    _lib.check(lib.vt_gemv_t(A.data_ptr(), dev.ld(A), u.data_ptr(), N, D, out.data_ptr(),
                              ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_gemv_t")
     return out
 
@@ -42,7 +42,7 @@ def gemv(A, v):
     v = v.contiguous()
     out = torch.empty(N, dtype=torch.float64, device=A.device)
     ws = _workspace(D, A.device)
-    _lib.check(lib.vt_gemv(A.data_ptr(), A.stride(0), v.data_ptr(), N, D, out.data_ptr(),
+    _lib.check(lib.vt_gemv(A.data_ptr(), dev.ld(A), v.data_ptr(), N, D, out.data_ptr(),
                            ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_gemv")
     return out
 
@@ -54,7 +54,7 @@ def gemv_t2(A, u1, u2):
     N, D = A.shape
     out = torch.empty(D, dtype=torch.float64, device=A.device)
     ws = _workspace(D, A.device)
-    _lib.check(lib.vt_gemv_t2(A.data_ptr(), A.stride(0), u1.contiguous().data_ptr(), u2.contiguous().data_ptr(),
+    _lib.check(lib.vt_gemv_t2(A.data_ptr(), dev.ld(A), u1.contiguous().data_ptr(), u2.contiguous().data_ptr(),
                               N, D, out.data_ptr(), ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_gemv_t2")
     return out
 
@@ -65,7 +65,7 @@ def glm_taylor2_rhs(obj, z, w, dw, u):
     lib = dev.require_gpu()
     out = torch.empty(obj.D, dtype=torch.float64, device=obj.device)
     ws = _workspace(obj.D, obj.device)
-    _lib.check(lib.vt_glm_taylor2_rhs(_lib.FAMILY[obj.family], obj.X.data_ptr(), obj.X.stride(0), z.data_ptr(),
+    _lib.check(lib.vt_glm_taylor2_rhs(_lib.FAMILY[obj.family], obj.X.data_ptr(), dev.ld(obj.X), z.data_ptr(),
                                       w.contiguous().data_ptr(), dw.contiguous().data_ptr(), obj.scale,
                                       u.contiguous().data_ptr(), obj.N, obj.D, out.data_ptr(), ws.data_ptr(),
                                       ws.numel() * 8, dev.stream_ptr()), "vt_glm_taylor2_rhs")
@@ -95,8 +95,8 @@ def gemm_tn(A, B, rowscale=None, alpha=1.0, bias=None, out=None):
         _tn_ws_cache[key] = ws
     if out is None:
         out = torch.empty((Da, Db), dtype=torch.float64, device=A.device)
-    _lib.check(lib.vt_gemm_tn(A.data_ptr(), A.stride(0), Da, B.data_ptr(), B.stride(0), Db, dev.ptr(rowscale),
-                              N, float(alpha), dev.ptr(bias), out.data_ptr(), out.stride(0), ws.data_ptr(),
+    _lib.check(lib.vt_gemm_tn(A.data_ptr(), dev.ld(A), Da, B.data_ptr(), dev.ld(B), Db, dev.ptr(rowscale),
+                              N, float(alpha), dev.ptr(bias), out.data_ptr(), dev.ld(out), ws.data_ptr(),
                               ws.numel() * 8, dev.stream_ptr()), "vt_gemm_tn")
     return out
 
@@ -110,7 +110,7 @@ def glm_link(obj, theta, w, want_z=False):
     r = torch.empty(obj.N, dtype=torch.float64, device=obj.device)
     d = torch.empty(obj.N, dtype=torch.float64, device=obj.device)
     ws = _workspace(obj.D, obj.device)
-    _lib.check(lib.vt_glm_link(_lib.FAMILY[obj.family], obj.X.data_ptr(), obj.X.stride(0), theta.data_ptr(),
+    _lib.check(lib.vt_glm_link(_lib.FAMILY[obj.family], obj.X.data_ptr(), dev.ld(obj.X), theta.data_ptr(),
                                obj.y.data_ptr(), w.data_ptr(), dev.ptr(obj.offset), obj.scale, obj.N, obj.D,
                                dev.ptr(z), r.data_ptr(), d.data_ptr(), ws.data_ptr(), ws.numel() * 8,
                                dev.stream_ptr()), "vt_glm_link")
@@ -126,7 +126,7 @@ def glm_grad(obj, theta, w, prior=None):
     r = torch.empty(obj.N, dtype=torch.float64, device=obj.device)
     d = torch.empty(obj.N, dtype=torch.float64, device=obj.device)
     ws = _workspace(obj.D, obj.device)
-    _lib.check(lib.vt_glm_grad(_lib.FAMILY[obj.family], obj.X.data_ptr(), obj.X.stride(0), theta.data_ptr(),
+    _lib.check(lib.vt_glm_grad(_lib.FAMILY[obj.family], obj.X.data_ptr(), dev.ld(obj.X), theta.data_ptr(),
                                obj.y.data_ptr(), w.data_ptr(), dev.ptr(obj.offset), obj.scale, dev.ptr(prior),
                                obj.N, obj.D, g.data_ptr(), r.data_ptr(), d.data_ptr(), ws.data_ptr(),
                                ws.numel() * 8, dev.stream_ptr()), "vt_glm_grad")
@@ -140,7 +140,7 @@ def glm_hvp(X, d, v, prior=None, prior_scalar=0.0, out=None):
     if out is None:
         out = torch.empty(D, dtype=torch.float64, device=X.device)
     ws = _workspace(D, X.device)
-    _lib.check(lib.vt_glm_hvp(X.data_ptr(), X.stride(0), d.data_ptr(), dev.ptr(prior), float(prior_scalar),
+    _lib.check(lib.vt_glm_hvp(X.data_ptr(), dev.ld(X), d.data_ptr(), dev.ptr(prior), float(prior_scalar),
                               v.data_ptr(), N, D, out.data_ptr(), ws.data_ptr(), ws.numel() * 8,
                               dev.stream_ptr()), "vt_glm_hvp")
     return out
@@ -153,7 +153,7 @@ def glm_value(obj, theta, w):
     w = dev.to_device(w, obj.device).contiguous()
     val = torch.empty(1, dtype=torch.float64, device=obj.device)
     ws = _workspace(obj.D, obj.device)
-    _lib.check(lib.vt_glm_value(_lib.FAMILY[obj.family], obj.X.data_ptr(), obj.X.stride(0), theta.data_ptr(),
+    _lib.check(lib.vt_glm_value(_lib.FAMILY[obj.family], obj.X.data_ptr(), dev.ld(obj.X), theta.data_ptr(),
                                 obj.y.data_ptr(), w.data_ptr(), dev.ptr(obj.offset), obj.scale, obj.N, obj.D,
                                 val.data_ptr(), ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_glm_value")
     obj._all_reduce(val)
