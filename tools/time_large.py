@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import vittles_amd as va
 from vittles_amd.linalg import DeviceCholesky
-def timeit(fn, reps=3):
+def timeit(fn, reps=10):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

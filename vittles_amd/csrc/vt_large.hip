@@ -133,7 +133,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a) {
 // stages of 16 k in rotation, 8 waves (2 per SIMD) of 64x32 accumulators per 128x128 tile.
 typedef __attribute__((address_space(3))) void* vt_ldsptr;
 constexpr int kKC = 16;                        // k per stage
-constexpr int kStages = 3;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rsrc(const double* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
@@ -146,10 +145,10 @@ __device__ __forceinline__ void lg_wait4_barrier() {
 
 // C = beta C + alpha A B^T.  LDS panel layout [k/2][row][2]: one DMA instruction moves (64 rows) x
 // (2 k) and MFMA operand reads (lane = row, k) are bank-conflict free.
-template <bool LOWER>
+template <bool LOWER, int STAGES>
 __global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
     if (LOWER && blockIdx.y > blockIdx.x) return;
-    extern __shared__ double lds[];            // [kStages][A: 8 planes x 128 rows x 2 | B: same]
+    extern __shared__ double lds[];            // [STAGES][A: 8 planes x 128 rows x 2 | B: same]
     constexpr int PANEL = (kKC / 2) * kT * 2;  // 2048 doubles
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -186,12 +185,18 @@ __global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
         for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
     issue(0, 0);
-    issue(1, 1);
+    if constexpr (STAGES == 3) issue(1, 1);
     int buf = 0;
     for (int t = 0; t < nk; ++t) {
-        lg_wait4_barrier();
-        const int b2 = buf == 0 ? 2 : buf - 1;     // (buf + 2) % 3
-        issue(t + 2, b2);
+        if constexpr (STAGES == 3) {
+            lg_wait4_barrier();
+            const int b2 = buf == 0 ? 2 : buf - 1;     // (buf + 2) % 3
+            issue(t + 2, b2);
+        } else {
+            // two stages (64 KB): two workgroups per CU cover each other's waits
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue(t + 1, buf ^ 1);
+        }
         const double* pa = lds + buf * (2 * PANEL) + (q >> 1) * (kT * 2) + (64 * wm + c) * 2 + (q & 1);
         const double* pb = lds + buf * (2 * PANEL) + PANEL + (q >> 1) * (kT * 2) + (32 * wn + c) * 2 + (q & 1);
 #pragma unroll
@@ -206,7 +211,8 @@ __global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
         }
-        buf = buf == 2 ? 0 : buf + 1;
+        if constexpr (STAGES == 3) buf = buf == 2 ? 0 : buf + 1;
+        else buf ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-filled look-ahead stages
 #pragma unroll
@@ -228,6 +234,12 @@ __global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
         }
 }
 
+static int large_stages() {
+    // default 2: measured 48.6 vs 43.2 TFLOP/s (SYRK, N = 1.25e6, D = 1000); VT_LARGE_STAGES=3 for A/B runs
+    static const int st = getenv("VT_LARGE_STAGES") ? atoi(getenv("VT_LARGE_STAGES")) : 2;
+    return st == 3 ? 3 : 2;
+}
+
 bool lds_path_ok(const double* A, int64_t lda, const double* B, int64_t ldb, int K) {
     return K % 2 == 0 && lda % 2 == 0 && ldb % 2 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
            !getenv("VT_LARGE_NO_LDS");
@@ -240,18 +252,25 @@ int gemm_nt(double* C, int64_t ldc, int64_t M, int N, const double* A, int64_t l
     GemmArgs a{C, ldc, M, N, A, lda, B, ldb, K, alpha, beta, Csrc, ldcs, rowscale, cscale};
     dim3 grid((unsigned)((M + kT - 1) / kT), (unsigned)((N + kT - 1) / kT));
     if (lds_path_ok(A, lda, B, ldb, K)) {
-        const size_t shmem = (size_t)kStages * 2 * (kKC / 2) * kT * 2 * sizeof(double);   // 96 KB
+        const int stages = large_stages();
+        const size_t shmem = (size_t)stages * 2 * (kKC / 2) * kT * 2 * sizeof(double);   // 96 / 64 KB
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)k_gemm_nt_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)shmem) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_gemm_nt_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)shmem) != hipSuccess)
+            const int mx = 3 * 2 * (kKC / 2) * kT * 2 * (int)sizeof(double);
+            if (hipFuncSetAttribute((const void*)k_gemm_nt_lds<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_gemm_nt_lds<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_gemm_nt_lds<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_gemm_nt_lds<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
                 return VT_ERR_HIP;
             attr_set = true;
         }
-        if (lower) hipLaunchKernelGGL((k_gemm_nt_lds<true>), grid, dim3(512), shmem, st, a);
-        else hipLaunchKernelGGL((k_gemm_nt_lds<false>), grid, dim3(512), shmem, st, a);
+        if (stages == 2) {
+            if (lower) hipLaunchKernelGGL((k_gemm_nt_lds<true, 2>), grid, dim3(512), shmem, st, a);
+            else hipLaunchKernelGGL((k_gemm_nt_lds<false, 2>), grid, dim3(512), shmem, st, a);
+        } else {
+            if (lower) hipLaunchKernelGGL((k_gemm_nt_lds<true, 3>), grid, dim3(512), shmem, st, a);
+            else hipLaunchKernelGGL((k_gemm_nt_lds<false, 3>), grid, dim3(512), shmem, st, a);
+        }
         return vt_launch_status();
     }
     bool vec = (K % 4 == 0) && K >= 4;
@@ -376,9 +395,11 @@ __global__ __launch_bounds__(256) void k_syrk_tile(SyrkArgs a) {
 
 // LDS-staged version: panels [n][col] (row stride 144 doubles = 16 mod 32: conflict-free operand
 // reads), one DMA instruction per row of a panel, d_n fetched a stage ahead.
-template <bool GEN>
+// STAGES = 3: one workgroup per CU, DMA two stages ahead.  STAGES = 2: 72 KB of LDS, so TWO workgroups
+// share a CU (4 waves per SIMD) and cover each other's barrier and DMA waits.
+template <bool GEN, int STAGES>
 __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
-    extern __shared__ double lds[];            // [kStages][I: 16 x 144 | J: 16 x 144]
+    extern __shared__ double lds[];            // [STAGES][I: 16 x 144 | J: 16 x 144]
     constexpr int RSTR = kT + 16, PANEL = kKC * RSTR;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -430,14 +451,22 @@ __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
     double dcur[4], dnxt[4];
     load_d(0, dcur);
     issue(0, 0);
-    issue(1, 1);
+    if constexpr (STAGES == 3) issue(1, 1);
     int buf = 0;
     for (int t = 0; t < nk; ++t) {
-        lg_wait4_barrier();
+        if constexpr (STAGES == 3) {
+            lg_wait4_barrier();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         load_d(t + 1, dnxt);                       // before the DMA issue: the newest 4 stay the DMAs
         __builtin_amdgcn_sched_barrier(0);
-        const int b2 = buf == 0 ? 2 : buf - 1;
-        issue(t + 2, b2);
+        if constexpr (STAGES == 3) {
+            const int b2 = buf == 0 ? 2 : buf - 1;
+            issue(t + 2, b2);
+        } else {
+            issue(t + 1, buf ^ 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (!skip) {
             const double* pa = lds + buf * (2 * PANEL) + q * RSTR + 64 * wm + c;
@@ -457,7 +486,8 @@ __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) dcur[s] = dnxt[s];
-        buf = buf == 2 ? 0 : buf + 1;
+        if constexpr (STAGES == 3) buf = buf == 2 ? 0 : buf + 1;
+        else buf ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -616,7 +646,7 @@ int vt_large_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, co
 // Split of the N axis: one 512-thread workgroup per CU at a time, so pick the split whose grid
 // (ntl * ks workgroups) fills whole rounds of the chip best.
 static int syrk_split(int ntl, int ks_max = 64) {
-    const int cu = num_cu();
+    const int cu = num_cu() * (large_stages() == 2 ? 2 : 1);   // workgroups resident at a time
     int best = 1;
     double best_eff = 0.0;
     for (int ks = 1; ks <= ks_max; ++ks) {
@@ -647,15 +677,18 @@ int vt_large_syrk(const double* X, int64_t ldx, const double* d, int64_t N, int 
     if (N == 0) {
         ks = 0;   // no rows: the reduce below sums zero slabs and adds the prior
     } else if (ldx % 2 == 0 && (uintptr_t)X % 16 == 0 && !getenv("VT_LARGE_NO_LDS")) {
-        const size_t shmem = (size_t)kStages * 2 * kKC * (kT + 16) * sizeof(double);   // 108 KB
+        const size_t shmem = (size_t)large_stages() * 2 * kKC * (kT + 16) * sizeof(double);   // 108 / 72 KB
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)k_syrk_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void*)k_syrk_lds<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)shmem) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_syrk_lds<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)shmem) != hipSuccess)
                 return VT_ERR_HIP;
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_syrk_lds<false>, dim3(ntl, ks), dim3(512), shmem, st, a);
+        if (large_stages() == 2) hipLaunchKernelGGL((k_syrk_lds<false, 2>), dim3(ntl, ks), dim3(512), shmem, st, a);
+        else hipLaunchKernelGGL((k_syrk_lds<false, 3>), dim3(ntl, ks), dim3(512), shmem, st, a);
     } else {
         hipLaunchKernelGGL(k_syrk_tile<false>, dim3(ntl, ks), dim3(256), 0, st, a);
     }
@@ -694,15 +727,18 @@ extern "C" int vt_gemm_tn(const double* A, int64_t lda, int Da, const double* B,
     if (N == 0) {
         ks = 0;   // no rows: C = bias
     } else if (lda % 2 == 0 && ldb % 2 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0 && !getenv("VT_LARGE_NO_LDS")) {
-        const size_t shmem = (size_t)kStages * 2 * kKC * (kT + 16) * sizeof(double);   // 108 KB
+        const size_t shmem = (size_t)large_stages() * 2 * kKC * (kT + 16) * sizeof(double);   // 108 / 72 KB
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)k_syrk_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void*)k_syrk_lds<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)shmem) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_syrk_lds<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)shmem) != hipSuccess)
                 return VT_ERR_HIP;
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_syrk_lds<true>, dim3(ntl, ks), dim3(512), shmem, st, a);
+        if (large_stages() == 2) hipLaunchKernelGGL((k_syrk_lds<true, 2>), dim3(ntl, ks), dim3(512), shmem, st, a);
+        else hipLaunchKernelGGL((k_syrk_lds<true, 3>), dim3(ntl, ks), dim3(512), shmem, st, a);
     } else {
         hipLaunchKernelGGL(k_syrk_tile<true>, dim3(ntl, ks), dim3(256), 0, st, a);
     }
