@@ -29,6 +29,8 @@
  *   H   : (D, D) row-major, FULL symmetric storage, leading dimension ldh.
  *   L   : lower Cholesky factor, H = L L^T, row-major in the lower triangle
  *         (== the transpose of scipy.linalg.cho_factor's default upper factor).
+ *   N   : may be 0 (an empty data set): the row pointers (X, y, w, ...) may then be NULL and the
+ *         results are those of an empty sum (H = prior, g = prior .* theta, no rows of S).
  *   S   : (N, D) row-major, row n = d theta-hat / d w_n.  Viewed transposed this
  *         is the reference's (D, N) `_sens_mat`, F-contiguous exactly as
  *         scipy.linalg.cho_solve returns it.
