@@ -499,22 +499,32 @@ __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
                 out[(wm * 64 + 16 * i + q + 4 * r) * kT + wn * 32 + 16 * j + c] = acc[i][j][r];
 }
 
-// H[i][j] = H[j][i] = sum_chunks part (+ prior on the diagonal), i >= j.
-__global__ void k_syrk_reduce(const double* part, int nt, int ksplit, int D, const double* prior, double* H,
-                              int ldh) {
-    int t = blockIdx.x, ti = 0;
+// H[i][j] = H[j][i] = sum_chunks part (+ prior on the diagonal), i >= j.  One thread per element,
+// slabs summed in a fixed order.
+__global__ __launch_bounds__(256) void k_syrk_reduce(const double* part, int nt, int ksplit, int D,
+                                                     const double* prior, double* H, int ldh) {
+    int t = blockIdx.y, ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     const int tj = t - ti * (ti + 1) / 2;
     const int ntl = nt * (nt + 1) / 2;
-    for (int e = threadIdx.x; e < kT * kT; e += blockDim.x) {
-        int i = ti * kT + e / kT, j = tj * kT + e % kT;
-        if (i >= D || j >= D || j > i) continue;
-        double s = 0.0;
-        for (int k = 0; k < ksplit; ++k) s += part[((int64_t)k * ntl + t) * (kT * kT) + e];
-        if (i == j && prior) s += prior[i];
-        H[(int64_t)i * ldh + j] = s;
-        H[(int64_t)j * ldh + i] = s;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int i = ti * kT + e / kT, j = tj * kT + e % kT;
+    if (i >= D || j >= D || j > i) return;
+    const double* p = part + (int64_t)t * (kT * kT) + e;
+    const int64_t stride = (int64_t)ntl * (kT * kT);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 4 <= ksplit; k += 4) {
+        s0 += p[(k + 0) * stride];
+        s1 += p[(k + 1) * stride];
+        s2 += p[(k + 2) * stride];
+        s3 += p[(k + 3) * stride];
     }
+    for (; k < ksplit; ++k) s0 += p[k * stride];
+    double s = (s0 + s1) + (s2 + s3);
+    if (i == j && prior) s += prior[i];
+    H[(int64_t)i * ldh + j] = s;
+    H[(int64_t)j * ldh + i] = s;
 }
 
 // C[i][j] = alpha * sum_chunks part + bias[j]   (i < Da, j < Db): the two-operand product's epilogue.
@@ -692,7 +702,8 @@ int vt_large_syrk(const double* X, int64_t ldx, const double* d, int64_t N, int 
     } else {
         hipLaunchKernelGGL(k_syrk_tile<false>, dim3(ntl, ks), dim3(256), 0, st, a);
     }
-    hipLaunchKernelGGL(k_syrk_reduce, dim3(ntl), dim3(1024), 0, st, (const double*)ws, nt, ks, D, prior, H, ldh);
+    hipLaunchKernelGGL(k_syrk_reduce, dim3(kT * kT / 256, ntl), dim3(256), 0, st, (const double*)ws, nt, ks, D, prior, H,
+                       ldh);
     return vt_launch_status();
 }
 
