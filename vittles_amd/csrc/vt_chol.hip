@@ -473,9 +473,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
         }
     };
 
+    constexpr bool PREFETCH = WAVES <= 8;   // more waves per SIMD: no register room for (nor need of) a prefetched tile
     int64_t grp = gw;
-    if (grp < ngroups) load_group(grp);
+    if (PREFETCH && grp < ngroups) load_group(grp);
     for (; grp < ngroups; grp += W) {
+        if constexpr (!PREFETCH) load_group(grp);
 #pragma unroll
         for (int b = 0; b < NB; ++b) st.V[b] = Gn[b] * coefn;
         int64_t row = grp * 16 + n;
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
         st.store_fwd = rowok && a.mode == 1;
         st.store_bwd = rowok && a.mode != 1;
         st.orow = a.Out + (rowok ? row : 0) * a.ldo;
-        load_group(grp + W < ngroups ? grp + W : grp);
+        if constexpr (PREFETCH) load_group(grp + W < ngroups ? grp + W : grp);
         if (a.mode != 2) {   // forward substitution  L Y = G
             constexpr int img = S::image(0);
             constexpr int nks = S::ks(S::src(0));
@@ -515,7 +517,12 @@ int num_cu() {
 // Two waves per SIMD, one 16-row tile each: everything a wave keeps outside the
 // accumulator must fit the 256 architectural VGPRs, and the partner wave's MFMA
 // chain fills this wave's load / dependency stalls.
-constexpr int kTrsmWaves = 8;
+// dev A/B (tools/build_abl.cmd): 12 / 16 waves (3 / 4 per SIMD, no tile prefetch, 168 / 128 VGPRs) measured
+// 0.415 / 0.438 ms against 0.400 ms for 8 waves with the prefetched tile at N = 1e6, D = 100.
+#ifndef VT_TRSM_WAVES
+#define VT_TRSM_WAVES 8
+#endif
+constexpr int kTrsmWaves = VT_TRSM_WAVES;
 
 template <int NB, int KL, bool LASTPERM>
 void launch_trsm(const TrsmArgs& a, hipStream_t st) {
