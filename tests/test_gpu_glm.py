@@ -172,7 +172,7 @@ def test_row_kernels(relerr):
         assert abs(val - ref) <= TOL * abs(ref), (N, D)
 
 
-@pytest.mark.parametrize("D,K", [(1, 1), (20, 1), (100, 1), (100, 5), (128, 3)])
+@pytest.mark.parametrize("D,K", [(1, 1), (20, 1), (100, 1), (100, 5), (128, 3), (300, 2)])
 def test_vt_potrs_generic_kernel_direct(D, K, relerr):
     """The generic substitution kernel through the C-ABI (DeviceCholesky.solve routes small D to the
     MFMA tile kernel, so it is called directly here)."""

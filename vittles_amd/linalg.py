@@ -88,18 +88,19 @@ class DeviceCholesky:
         if v.shape[0] != self.D:
             raise ValueError("incompatible dimensions: factor is %dx%d, b has %d rows"
                              % (self.D, self.D, v.shape[0]))
-        small = self.D <= _lib.SMALL_D_MAX
+        # Every D the MFMA TRSM covers goes through it, one 16-row tile for a single right-hand side: the
+        # generic one-wave substitution (vt_potrs) costs 0.1 ms at D = 100 and 4 ms at D = 1000, the tile
+        # kernels 0.015 / 0.3 ms (the operand pack is built once per factor and cached).
+        tiled = lib.vt_trsm_pack_bytes(self.D) > 0
         if v.ndim == 1:
-            if small:
-                # one 16-row tile of the MFMA TRSM (pack resident in LDS): ~6x faster than the generic
-                # one-wave substitution for a single right-hand side
+            if tiled:
                 return self.solve_rows(v.detach().reshape(1, self.D)).reshape(self.D)
             x = v.detach().clone().contiguous()
             _lib.check(lib.vt_potrs(self.L.data_ptr(), self.D, self.D, x.data_ptr(), 1, self.D, 1,
                                     dev.stream_ptr()), "vt_potrs")
             return x
         K = v.shape[1]
-        if (small or K >= 64) and lib.vt_trsm_pack_bytes(self.D) > 0:
+        if tiled:
             # MFMA TRSM wants right-hand sides as rows: (K, D) row-major.
             rows = v.detach().t().contiguous()
             out = self.solve_rows(rows)
