@@ -416,12 +416,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
     using S = TrsmSched<NB, KL, LASTPERM>;
     constexpr int NBT = S::NBT;
     __shared__ double lds[2 * NBT * 256];
-    {
-        const f64x2u* src = (const f64x2u*)a.pack;
-        f64x2u* dst = (f64x2u*)lds;
-        for (int i = threadIdx.x; i < NBT * 256; i += WAVES * 64) dst[i] = src[i];
-    }
-    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -476,6 +470,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
     constexpr bool PREFETCH = WAVES <= 8;   // more waves per SIMD: no register room for (nor need of) a prefetched tile
     int64_t grp = gw;
     if (PREFETCH && grp < ngroups) load_group(grp);
+    {   // the pack -> LDS, behind the first tile's loads
+        const f64x2u* src = (const f64x2u*)a.pack;
+        f64x2u* dst = (f64x2u*)lds;
+        for (int i = threadIdx.x; i < NBT * 256; i += WAVES * 64) dst[i] = src[i];
+    }
+    __syncthreads();
     for (; grp < ngroups; grp += W) {
         if constexpr (!PREFETCH) load_group(grp);
 #pragma unroll
