@@ -144,11 +144,58 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(const double* Ain, int
         for (int rr = 0; rr < 4; ++rr) a[(ri + q + 4 * rr) * kSmallLd + rk + cl] = cacc[rr];
     };
 
+    // ---- TRSM operand pack (see vt_trsm_pack), one block pair at a time on the MFMA:
+    //      forward  F_ji = -Linv_jj L_ji,  backward  B_ji = -Linv_jj^T L_ij^T  (16x16x16 products), the
+    //      accumulator element (row, col) scattered to its slot of the A-operand image.  Everything a
+    //      pair of block row j needs (Linv_jj, block row j and block column j of L) is final one panel
+    //      step after j, so the rows are emitted inside the factorisation by the waves that idle there.
+    const bool lastperm = (D & 15) == 0;
+    auto emit_pair = [&](int j, int i, bool bwd) __attribute__((always_inline)) {
+        const int q = lane >> 4, c = lane & 15;
+        const int PI = bwd ? NBT + vt_tri(i, j) : vt_tri(j, i);
+        f64x4 m = {0.0, 0.0, 0.0, 0.0};
+        if (i == j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                m[r] = bwd ? linv[(j * 16 + c) * 17 + q + 4 * r] : linv[(j * 16 + q + 4 * r) * 17 + c];
+        } else {
+            double av[4], bv[4];
+#pragma unroll
+            for (int sstep = 0; sstep < 4; ++sstep) {
+                const int k = 4 * sstep + q;
+                if (!bwd) {
+                    av[sstep] = -linv[(j * 16 + c) * 17 + k];
+                    bv[sstep] = a[(16 * j + k) * kSmallLd + 16 * i + c];
+                } else {
+                    av[sstep] = -linv[(j * 16 + k) * 17 + c];
+                    bv[sstep] = a[(16 * i + c) * kSmallLd + 16 * j + k];
+                }
+            }
+#pragma unroll
+            for (int sstep = 0; sstep < 4; ++sstep) m = mfma_f64(av[sstep], bv[sstep], m);
+        }
+        const bool pj = j < NB - 1 || lastperm, pi = i < NB - 1 || lastperm;
+        const int kk = vt_perm(pi, c);                     // vt_perm is an involution
+        double* dst = pack + ((int64_t)PI * 4 + (kk >> 2)) * 64 + (kk & 3) * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[vt_perm(pj, q + 4 * r)] = m[r];
+    };
+    // the NB + 1 pairs of block row j: forward (j, 0..j), backward (j, j..NB-1); slot of nslots waves
+    auto emit_row = [&](int j, int slot, int nslots) {
+        for (int e = slot; e < NB + 1; e += nslots) {
+            if (e <= j) emit_pair(j, e, false);
+            else emit_pair(j, e - 1, true);
+        }
+    };
+
     if (!do_factor) {
         // A already holds L: only the inverted diagonal blocks are needed
         if (tid < NP) rdiag_s[tid] = vt_rcp(a[tid * kSmallLd + tid]);
         __syncthreads();
         for (int J = wave; J < NB; J += 4) diag_invert(J);
+        __syncthreads();
+        if (pack != nullptr)
+            for (int j = 0; j < NB; ++j) emit_row(j, wave, 4);
     } else {
         if (wave == 0 && !(VT_PABL & 1)) diag_factor(0);
         __syncthreads();
@@ -187,12 +234,21 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(const double* Ain, int
                         trailing_tile(o, bi, t - bi * (bi + 1) / 2);
                     }
                 }
-                if (wave == 1 && pack != nullptr) diag_invert(J);
+                if (pack != nullptr && !(VT_PABL & 8)) {
+                    if (wave == 1) diag_invert(J);
+                    else if (J >= 1) emit_row(J - 1, wave - 2, 2);   // block row J-1 has been final for a step
+                }
             }
             __syncthreads();
         }
-        // the last diagonal block was factored by the final look-ahead (or is block 0 when NB = 1)
-        if (pack != nullptr && !s_bad && wave == 0) diag_invert(NB - 1);
+        // the last diagonal block was factored by the final look-ahead (or is block 0 when NB = 1);
+        // block rows NB-2 and NB-1 of the pack are still to be emitted
+        if (pack != nullptr && !s_bad && !(VT_PABL & 8)) {
+            if (wave == 0) diag_invert(NB - 1);
+            else if (NB >= 2) emit_row(NB - 2, wave - 1, 3);
+            __syncthreads();
+            emit_row(NB - 1, wave, 4);
+        }
     }
     __syncthreads();
     const int bad = s_bad;
@@ -204,46 +260,6 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(const double* Ain, int
             else if (oop && j < D) A[(int64_t)i * lda + j] = 0.0;
         }
         if (tid == 0 && info) *info = bad;
-    }
-    if (pack == nullptr || bad || (VT_PABL & 8)) return;
-    // ---- TRSM operand pack (see vt_trsm_pack), one block pair per wave at a time, on the MFMA:
-    //      forward  F_ji = -Linv_jj L_ji,  backward  B_ji = -Linv_jj^T L_ij^T  (16x16x16 products), the
-    //      accumulator element (row, col) scattered to its slot of the A-operand image -----------------
-    const bool lastperm = (D & 15) == 0;
-    const int q = lane >> 4, c = lane & 15;
-    for (int PI = wave; PI < 2 * NBT; PI += 4) {
-        const bool bwd = PI >= NBT;
-        const int t = bwd ? PI - NBT : PI;
-        int hi = 0;
-        while ((hi + 1) * (hi + 2) / 2 <= t) ++hi;
-        const int lo = t - hi * (hi + 1) / 2;
-        const int j = bwd ? lo : hi, i = bwd ? hi : lo;
-        f64x4 m = {0.0, 0.0, 0.0, 0.0};
-        if (i == j) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                m[r] = bwd ? linv[(j * 16 + c) * 17 + q + 4 * r] : linv[(j * 16 + q + 4 * r) * 17 + c];
-        } else {
-            double av[4], bv[4];
-#pragma unroll
-            for (int sstep = 0; sstep < 4; ++sstep) {
-                const int k = 4 * sstep + q;
-                if (!bwd) {
-                    av[sstep] = -linv[(j * 16 + c) * 17 + k];
-                    bv[sstep] = a[(16 * j + k) * kSmallLd + 16 * i + c];
-                } else {
-                    av[sstep] = -linv[(j * 16 + k) * 17 + c];
-                    bv[sstep] = a[(16 * i + c) * kSmallLd + 16 * j + k];
-                }
-            }
-#pragma unroll
-            for (int sstep = 0; sstep < 4; ++sstep) m = mfma_f64(av[sstep], bv[sstep], m);
-        }
-        const bool pj = j < NB - 1 || lastperm, pi = i < NB - 1 || lastperm;
-        const int kk = vt_perm(pi, c);                     // vt_perm is an involution
-        double* dst = pack + ((int64_t)PI * 4 + (kk >> 2)) * 64 + (kk & 3) * 16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dst[vt_perm(pj, q + 4 * r)] = m[r];
     }
 }
 
