@@ -37,8 +37,8 @@ def link3(family, z):
 def input_derivs(family, X, y, theta, w, dw, prior=None, scale=1.0, offset=None, max_order=2):
     """[d theta/dw . dw,  d^2 theta/dw^2 [dw, dw]] at (theta, w) (reference: evaluate_input_derivs,
     sensitivity_lib.py:1273-1285)."""
-    if max_order not in (1, 2):
-        raise ValueError("oracle covers orders 1 and 2")
+    if max_order < 1 or (max_order > 2 and family != "gaussian"):
+        raise ValueError("oracle covers orders 1 and 2 (any order for the gaussian family)")
     z = glm.linear_predictor(X, theta, offset)
     _, l1, _ = glm.link(family, z, y)
     l2, l3 = link3(family, z)
@@ -48,6 +48,10 @@ def input_derivs(family, X, y, theta, w, dw, prior=None, scale=1.0, offset=None,
     if max_order >= 2:
         t = X @ d1
         rhs = X.T @ (scale * (w * l3 * t * t + 2.0 * dw * l2 * t))
+        out.append(-scipy.linalg.cho_solve(chol, rhs))
+    for k in range(3, max_order + 1):
+        # gaussian: G bilinear in (theta, w)  =>  H d_k + k G_tw[d_{k-1}, dw] = 0
+        rhs = k * (X.T @ (scale * dw * (X @ out[-1])))
         out.append(-scipy.linalg.cho_solve(chol, rhs))
     return out
 

@@ -191,12 +191,21 @@ def test_taylor_expansion_reference_regression_kat():
     d1_fn = lambda w: torch.func.jvp(run, (w,), (dw,))[1]
     d1 = d1_fn(w1).numpy()
     d2 = torch.func.jvp(d1_fn, (w1,), (dw,))[1].numpy()
+    d2_fn = lambda w: torch.func.jvp(d1_fn, (w,), (dw,))[1]
+    d3_fn = lambda w: torch.func.jvp(d2_fn, (w,), (dw,))[1]
+    d3 = d3_fn(w1).numpy()
+    d4 = torch.func.jvp(d3_fn, (w1,), (dw,))[1].numpy()
     obj = va.WeightedGLMObjective(x, y, family="gaussian", prior=None, scale=2.0)
     te = va.ParametricSensitivityTaylorExpansion.optimization_objective(
-        objective_function=obj, input_val0=theta0, hyper_val0=w1.numpy(), order=2,
+        objective_function=obj, input_val0=theta0, hyper_val0=w1.numpy(), order=4,
         max_hyper_order=1, max_input_order=2, forward_mode=False)
     w_new = (w1 + dw).numpy()
     np.testing.assert_array_almost_equal(te.evaluate_taylor_series(w_new, max_order=1), theta0 + d1)
     np.testing.assert_array_almost_equal(te.evaluate_taylor_series(w_new, max_order=2), theta0 + d1 + d2 / 2.0)
-    with pytest.raises(NotImplementedError):
-        va.ParametricSensitivityTaylorExpansion.optimization_objective(obj, theta0, w1.numpy(), order=4)
+    np.testing.assert_array_almost_equal(te.evaluate_taylor_series(w_new, max_order=3),
+                                         theta0 + d1 + d2 / 2.0 + d3 / 6.0)
+    np.testing.assert_array_almost_equal(te.evaluate_taylor_series(w_new, max_order=4),
+                                         theta0 + d1 + d2 / 2.0 + d3 / 6.0 + d4 / 24.0)
+    lg = va.WeightedGLMObjective(x, (y > 0).astype(float), family="logistic", prior=1.0)
+    with pytest.raises(NotImplementedError):          # non-gaussian families stop at order 2
+        va.ParametricSensitivityTaylorExpansion.optimization_objective(lg, theta0, w1.numpy(), order=3)

@@ -299,9 +299,14 @@ def test_taylor_oracle_weighted_regression_kat():
     d1_fn = lambda w: torch.func.jvp(run, (w,), (dw,))[1]
     d1 = d1_fn(w1).numpy()
     d2 = torch.func.jvp(d1_fn, (w1,), (dw,))[1].numpy()
-    got = taylor.input_derivs("gaussian", x, y, theta0, w1.numpy(), dw.numpy(), prior=None, scale=2.0)
+    d2_fn = lambda w: torch.func.jvp(d1_fn, (w,), (dw,))[1]
+    d3_fn = lambda w: torch.func.jvp(d2_fn, (w,), (dw,))[1]
+    d3 = d3_fn(w1).numpy()
+    d4 = torch.func.jvp(d3_fn, (w1,), (dw,))[1].numpy()
+    got = taylor.input_derivs("gaussian", x, y, theta0, w1.numpy(), dw.numpy(), prior=None, scale=2.0, max_order=4)
     rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
     assert rel(got[0], d1) < 1e-10 and rel(got[1], d2) < 1e-10
+    assert rel(got[2], d3) < 1e-10 and rel(got[3], d4) < 1e-10          # orders 3 and 4 of the reference test
     series = taylor.taylor_series("gaussian", x, y, theta0, w1.numpy(), (w1 + dw).numpy(), None, 2.0)
     assert rel(series, theta0 + d1 + d2 / 2.0) < 1e-12
 

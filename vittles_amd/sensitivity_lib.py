@@ -282,7 +282,9 @@ class ParametricSensitivityTaylorExpansion:
     hyper-parameter.  The reference expands an arbitrary estimating equation to arbitrary order
     with nested ``autograd.make_jvp`` calls; this build covers what has a fixed kernel shape
     (SURVEY.md section 8f, rank 4): **data weights of a registered ``WeightedGLMObjective``,
-    orders 1 and 2**, each order one streaming pass over X plus one Cholesky solve:
+    orders 1 and 2** (any order for the gaussian family, whose higher link derivatives vanish --
+    the reference's own order-4 regression test runs), each order one streaming pass over X plus
+    one Cholesky solve:
 
         d1 = -H^{-1} X^T (r .* dw)
         d2 = -H^{-1} X^T scale (w ell''' t^2 + 2 dw ell'' t),   t = X d1
@@ -324,8 +326,10 @@ class ParametricSensitivityTaylorExpansion:
             raise ValueError('max_hyper_order must be >= 1.')
         if order < 1:
             raise ValueError('order must be at least one.')
-        if order > 2:
-            raise NotImplementedError('Taylor orders above 2 are outside the MI355X hot path.')
+        if order > 2 and obj.family != 'gaussian':
+            raise NotImplementedError(
+                'Taylor orders above 2 are built for the gaussian family only (its higher link '
+                'derivatives vanish); other families stop at order 2.')
         self._obj = obj
         self._input_val0 = deepcopy(input_val0)
         self._hyper_val0 = deepcopy(hyper_val0)
@@ -363,8 +367,13 @@ class ParametricSensitivityTaylorExpansion:
         obj = self._obj
         if k == 1:
             vec = rows.gemv_t2(obj.X, self._r, dhyper)
-        else:
+        elif k == 2:
             vec = rows.glm_taylor2_rhs(obj, self._z, self._w, dhyper, input_derivs[0])
+        else:
+            # gaussian family: G is bilinear in (theta, w), so the order-k equation is
+            # H d_k + k (d^2 G / d theta d w)[d_{k-1}, dw] = 0: one fused pass X^T (scale dw .* (X d_{k-1}))
+            dvec = dhyper if obj.scale == 1.0 else dhyper * obj.scale
+            vec = float(k) * rows.glm_hvp(obj.X, dvec, input_derivs[k - 2])
         obj._all_reduce(vec)            # row-sharded objective: partial sums over the ranks' rows
         return -1 * self._solve(vec)
 
