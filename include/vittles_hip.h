@@ -182,6 +182,15 @@ int    vt_glm_taylor2_rhs(int family, const double* X_dev, int64_t ldx, const do
                           const double* dw_dev, double scale, const double* u_dev, int64_t N, int D,
                           double* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* Third-order data-weight term of a GLM, one pass over X (zeta2_dev = X d2 from vt_gemv, u1 = d1):
+ *   out = scale * sum_n [ w_n (ell'''' z1^3 + 3 ell''' z1 z2) + 3 dw_n (ell''' z1^2 + ell'' z2) ] x_n,
+ *   z1 = x_n.d1, z2 = zeta2_n; the third directional derivative of the optimum is -H^{-1} out.
+ * Replaces: the order-3 terms of ParametricSensitivityTaylorExpansion._evaluate_dkinput_dhyperk
+ *             vittles/sensitivity_lib.py:1209-1260. */
+int    vt_glm_taylor3_rhs(int family, const double* X_dev, int64_t ldx, const double* z_dev, const double* w_dev,
+                          const double* dw_dev, const double* zeta2_dev, double scale, const double* u1_dev,
+                          int64_t N, int D, double* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
 /* K9, many weight vectors at once:  C (Da, Db) = alpha * A^T diag(s) B + 1 bias^T  for row-major
  * A (N, Da), B (N, Db); s (N,) and bias (Db,) may be NULL.  fp64 MFMA, N axis split over the chip,
  * fixed-order reduction.  With A = the matrix whose COLUMNS are new weight vectors (bootstrap draws,

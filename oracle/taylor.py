@@ -34,11 +34,21 @@ def link3(family, z):
     raise ValueError(family)
 
 
+def link4(family, z):
+    """Fourth link derivative d^4 ell / dz^4."""
+    l2, _ = link3(family, z)
+    if family == "logistic":
+        return l2 * (1.0 - 6.0 * l2)
+    if family == "poisson":
+        return l2
+    return np.zeros_like(z)
+
+
 def input_derivs(family, X, y, theta, w, dw, prior=None, scale=1.0, offset=None, max_order=2):
     """[d theta/dw . dw,  d^2 theta/dw^2 [dw, dw]] at (theta, w) (reference: evaluate_input_derivs,
     sensitivity_lib.py:1273-1285)."""
-    if max_order < 1 or (max_order > 2 and family != "gaussian"):
-        raise ValueError("oracle covers orders 1 and 2 (any order for the gaussian family)")
+    if max_order < 1 or (max_order > 3 and family != "gaussian"):
+        raise ValueError("oracle covers orders 1 to 3 (any order for the gaussian family)")
     z = glm.linear_predictor(X, theta, offset)
     _, l1, _ = glm.link(family, z, y)
     l2, l3 = link3(family, z)
@@ -49,6 +59,14 @@ def input_derivs(family, X, y, theta, w, dw, prior=None, scale=1.0, offset=None,
         t = X @ d1
         rhs = X.T @ (scale * (w * l3 * t * t + 2.0 * dw * l2 * t))
         out.append(-scipy.linalg.cho_solve(chol, rhs))
+    if max_order >= 3 and family != "gaussian":
+        # third total derivative of (w + t dw) * dl(z(t)), z(t) = z + t z1 + t^2/2 z2 + t^3/6 z3, without the
+        # w l2 z3 term (that one is H d3):  w (l4 z1^3 + 3 l3 z1 z2) + 3 dw (l3 z1^2 + l2 z2)
+        z1, z2 = X @ out[0], X @ out[1]
+        l4 = link4(family, z)
+        rhs = X.T @ (scale * (w * (l4 * z1 ** 3 + 3.0 * l3 * z1 * z2) + 3.0 * dw * (l3 * z1 ** 2 + l2 * z2)))
+        out.append(-scipy.linalg.cho_solve(chol, rhs))
+        return out
     for k in range(3, max_order + 1):
         # gaussian: G bilinear in (theta, w)  =>  H d_k + k G_tw[d_{k-1}, dw] = 0
         rhs = k * (X.T @ (scale * dw * (X @ out[-1])))

@@ -145,24 +145,27 @@ def test_taylor_expansion_orders_1_2_match_oracle(family, N, D, relerr):
     theta = glm.newton_optimum(family, X, y, w, prior=prior, scale=1.5)
     obj = va.WeightedGLMObjective(X, y, family=family, prior=prior, scale=1.5)
     te = va.ParametricSensitivityTaylorExpansion.optimization_objective(
-        objective_function=obj, input_val0=theta, hyper_val0=w, order=2)
-    assert te.get_max_order() == 2
-    d_ref = taylor.input_derivs(family, X, y, theta, w, dw, prior, 1.5)
+        objective_function=obj, input_val0=theta, hyper_val0=w, order=3)
+    assert te.get_max_order() == 3
+    d_ref = taylor.input_derivs(family, X, y, theta, w, dw, prior, 1.5, max_order=3)
     d_got = te.evaluate_input_derivs(dw)
-    assert len(d_got) == 2 and all(isinstance(d, np.ndarray) for d in d_got)
+    assert len(d_got) == 3 and all(isinstance(d, np.ndarray) for d in d_got)
+    if np.abs(d_ref[2]).max() > 0:
+        assert relerr(d_got[2], d_ref[2]) < 1e-10
+    assert len(te.evaluate_input_derivs(dw, max_order=2)) == 2
     assert relerr(d_got[0], d_ref[0]) < 1e-10
     if np.abs(d_ref[1]).max() > 0:
         assert relerr(d_got[1], d_ref[1]) < 1e-10
-    for mo in (1, 2):
+    for mo in (1, 2, 3):
         ref = taylor.taylor_series(family, X, y, theta, w, w + dw, prior, 1.5, max_order=mo)
         assert relerr(te.evaluate_taylor_series(w + dw, max_order=mo), ref) < 1e-10
     assert relerr(te.evaluate_taylor_series(w + dw, add_offset=False),
-                  taylor.taylor_series(family, X, y, theta, w, w + dw, prior, 1.5, add_offset=False)) < 1e-10
+                  taylor.taylor_series(family, X, y, theta, w, w + dw, prior, 1.5, add_offset=False, max_order=3)) < 1e-10
     # the first-order term is the linear approximation's prediction (sensitivity_lib.py:245-247)
     la = va.HyperparameterSensitivityLinearApproximation(obj, theta, w)
     assert relerr(te.evaluate_taylor_series(w + dw, max_order=1), la.predict_opt_par_from_hyper_par(w + dw)) < 1e-10
     with pytest.raises(ValueError):
-        te.evaluate_taylor_series(w + dw, max_order=3)
+        te.evaluate_taylor_series(w + dw, max_order=4)
     with pytest.raises(ValueError):
         te.evaluate_taylor_series(w + dw, max_order=0)
 
@@ -207,5 +210,5 @@ def test_taylor_expansion_reference_regression_kat():
     np.testing.assert_array_almost_equal(te.evaluate_taylor_series(w_new, max_order=4),
                                          theta0 + d1 + d2 / 2.0 + d3 / 6.0 + d4 / 24.0)
     lg = va.WeightedGLMObjective(x, (y > 0).astype(float), family="logistic", prior=1.0)
-    with pytest.raises(NotImplementedError):          # non-gaussian families stop at order 2
-        va.ParametricSensitivityTaylorExpansion.optimization_objective(lg, theta0, w1.numpy(), order=3)
+    with pytest.raises(NotImplementedError):          # non-gaussian families stop at order 3
+        va.ParametricSensitivityTaylorExpansion.optimization_objective(lg, theta0, w1.numpy(), order=4)

@@ -337,7 +337,7 @@ def test_taylor_oracle_vs_torch_ad_of_the_estimating_equation(family):
             ell = 0.5 * (z - yt) ** 2
         return 1.3 * (ww * ell).sum() + 0.5 * (pt * t ** 2).sum()
     G = torch.func.grad(f, 0)
-    d1, d2 = taylor.input_derivs(family, X, y, theta, w, dw, prior, 1.3)
+    d1, d2, d3 = taylor.input_derivs(family, X, y, theta, w, dw, prior, 1.3, max_order=3)
     tt, wt, dwt, d1t = (torch.tensor(a) for a in (theta, w, dw, d1))
     # second total derivative of G along (theta + s d1, w + s dw) minus the H d2 term
     path = lambda s: G(tt + s * d1t, wt + s * dwt)
@@ -350,3 +350,16 @@ def test_taylor_oracle_vs_torch_ad_of_the_estimating_equation(family):
     opt = lambda ww: glm.newton_optimum(family, X, y, ww, prior=prior, scale=1.3, iters=50)
     fd2 = (opt(w + eps * dw) - 2 * theta + opt(w - eps * dw)) / eps ** 2
     assert rel(d2, fd2) < 1e-5
+    # order 3: third total derivative of G along theta + s d1 + s^2/2 d2, w + s dw (nested forward-mode AD)
+    # equals -H d3; and d3 == a central third difference of the re-optimised optimum (loose)
+    d2t = torch.tensor(d2)
+    one = torch.ones((), dtype=torch.float64)
+    path3 = lambda s_: G(tt + s_ * d1t + 0.5 * s_ * s_ * d2t, wt + s_ * dwt)
+    f1 = lambda s_: torch.func.jvp(path3, (s_,), (one,))[1]
+    f2 = lambda s_: torch.func.jvp(f1, (s_,), (one,))[1]
+    third = torch.func.jvp(f2, (torch.zeros((), dtype=torch.float64),), (one,))[1]
+    assert rel(-H @ d3, third.numpy()) < 1e-10
+    if family != "gaussian":
+        e3 = 5e-2
+        fd3 = (opt(w + 2 * e3 * dw) - 2 * opt(w + e3 * dw) + 2 * opt(w - e3 * dw) - opt(w - 2 * e3 * dw)) / (2 * e3 ** 3)
+        assert rel(d3, fd3) < 5e-3

@@ -50,6 +50,8 @@ SIGNATURES = {
     "vt_gemv_t2": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size_t, c_ptr]),
     "vt_glm_taylor2_rhs": (c_int, [c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_dbl, c_ptr, c_i64, c_int, c_ptr,
                                    c_ptr, c_size_t, c_ptr]),
+    "vt_glm_taylor3_rhs": (c_int, [c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_ptr, c_i64, c_int, c_ptr,
+                                   c_ptr, c_size_t, c_ptr]),
     "vt_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vt_gemm_tn": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_dbl, c_ptr, c_ptr, c_i64,
                            c_ptr, c_size_t, c_ptr]),

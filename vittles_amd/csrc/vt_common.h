@@ -128,6 +128,18 @@ __device__ __forceinline__ void vt_link3(int family, double z, double& l2, doubl
     }
 }
 
+// l2 = ell'', l3 = ell''', l4 = ell''''.
+__device__ __forceinline__ void vt_link4(int family, double z, double& l2, double& l3, double& l4) {
+    vt_link3(family, z, l2, l3);
+    if (family == VT_FAMILY_LOGISTIC) {
+        l4 = l2 * (1.0 - 6.0 * l2);          // p (1 - p) (1 - 6 p (1 - p))
+    } else if (family == VT_FAMILY_POISSON) {
+        l4 = l2;
+    } else {
+        l4 = 0.0;
+    }
+}
+
 // Per-row loss value ell(z, y).
 __device__ __forceinline__ double vt_loss(int family, double z, double y) {
     if (family == VT_FAMILY_LOGISTIC) {

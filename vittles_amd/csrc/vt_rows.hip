@@ -19,7 +19,7 @@
 namespace {
 
 enum RowOp { OP_LINK = 0, OP_GRAD = 1, OP_HVP = 2, OP_GEMVT = 3, OP_VALUE = 4, OP_GEMV = 5, OP_GEMVT2 = 6,
-             OP_TAYLOR2 = 7 };
+             OP_TAYLOR2 = 7, OP_TAYLOR3 = 8 };
 
 struct RowArgs {
     const double* X;
@@ -42,7 +42,8 @@ struct RowArgs {
 template <int OP>
 struct OpTraits {
     static constexpr bool kDot = OP != OP_GEMVT && OP != OP_GEMVT2;
-    static constexpr bool kCols = OP == OP_GRAD || OP == OP_HVP || OP == OP_GEMVT || OP == OP_GEMVT2 || OP == OP_TAYLOR2;
+    static constexpr bool kCols = OP == OP_GRAD || OP == OP_HVP || OP == OP_GEMVT || OP == OP_GEMVT2 || OP == OP_TAYLOR2 ||
+                                  OP == OP_TAYLOR3;
     static constexpr bool kVal = OP == OP_VALUE;
 };
 
@@ -60,10 +61,11 @@ __device__ __forceinline__ RowScal load_scal(const RowArgs& a, int64_t n) {
     } else if constexpr (OP == OP_GEMVT2) {
         s.dv = a.dvec[n];
         s.y = a.y[n];
-    } else if constexpr (OP == OP_TAYLOR2) {
+    } else if constexpr (OP == OP_TAYLOR2 || OP == OP_TAYLOR3) {
         s.y = a.y[n];      // z_n (from vt_glm_link)
         s.w = a.w[n];
         s.dv = a.dvec[n];  // delta w_n
+        if constexpr (OP == OP_TAYLOR3) s.off = a.offset[n];   // zeta2_n = x_n . d2
     } else if constexpr (OP != OP_GEMV) {
         s.y = a.y[n];
         s.w = a.w[n];
@@ -84,6 +86,12 @@ __device__ __forceinline__ double row_op(const RowArgs& a, int64_t n, const RowS
         double l2, l3;
         vt_link3(a.family, s.y, l2, l3);
         return a.scale * (s.w * l3 * dot + 2.0 * s.dv * l2) * dot;
+    } else if constexpr (OP == OP_TAYLOR3) {
+        // third total derivative of (w + t dw) ell'(z + t zeta1 + t^2/2 zeta2 + ...) without the ell'' zeta3 term
+        double l2, l3, l4;
+        vt_link4(a.family, s.y, l2, l3, l4);
+        const double z1 = dot, z2 = s.off;
+        return a.scale * (s.w * (l4 * z1 * z1 * z1 + 3.0 * l3 * z1 * z2) + 3.0 * s.dv * (l3 * z1 * z1 + l2 * z2));
     } else if constexpr (OP == OP_GEMV) {
         if (lead) a.z_out[n] = dot;
         return 0.0;
@@ -482,12 +490,12 @@ int launch_cfg(const RowArgs& a, const RowCfg& c, int grid, bool nt, hipStream_t
             if (c.cpt == 5) return launch_wide<OP, 2, 5, 5>(a, grid, st);
             if (c.cpt == 10) return launch_wide<OP, 2, 10, 10>(a, grid, st);
             if (c.cpt == 15) return launch_wide<OP, 2, 15, 15>(a, grid, st);
-            if (c.cpt == 20) return launch_wide<OP, 2, 20, (OP == OP_GRAD || OP == OP_TAYLOR2 ? 6 : 10)>(a, grid, st);
+            if (c.cpt == 20) return launch_wide<OP, 2, 20, (OP == OP_GRAD || OP == OP_TAYLOR2 || OP == OP_TAYLOR3 ? 6 : 10)>(a, grid, st);
         } else {
             if (c.cpt == 10) return launch_wide<OP, 1, 10, 10>(a, grid, st);
             if (c.cpt == 20) return launch_wide<OP, 1, 20, 20>(a, grid, st);
             if (c.cpt == 30) return launch_wide<OP, 1, 30, 28>(a, grid, st);
-            if (c.cpt == 40) return launch_wide<OP, 1, 40, (OP == OP_GRAD || OP == OP_TAYLOR2 ? 8 : 20)>(a, grid, st);
+            if (c.cpt == 40) return launch_wide<OP, 1, 40, (OP == OP_GRAD || OP == OP_TAYLOR2 || OP == OP_TAYLOR3 ? 8 : 20)>(a, grid, st);
         }
     }
     return VT_ERR_UNSUPPORTED;
@@ -606,6 +614,20 @@ extern "C" int vt_glm_taylor2_rhs(int family, const double* X, int64_t ldx, cons
     if (N > 0) {
         RowArgs a{X, ldx, N, D, u, z, w, nullptr, dw, scale, family, nullptr, nullptr, nullptr, (double*)ws};
         P = run_rows<OP_TAYLOR2>(a, st);
+        if (P < 0) return P;
+    }
+    return finalize((const double*)ws, D, P, D, 0, 1.0, nullptr, nullptr, 0.0, out, st);
+}
+
+extern "C" int vt_glm_taylor3_rhs(int family, const double* X, int64_t ldx, const double* z, const double* w,
+                                  const double* dw, const double* zeta2, double scale, const double* u1,
+                                  int64_t N, int D, double* out, void* ws, size_t ws_bytes, void* stream) {
+    VT_ROWS_PROLOGUE
+    if (!u1 || !out || (N > 0 && (!z || !w || !dw || !zeta2))) return VT_ERR_BAD_ARG;
+    int P = 0;
+    if (N > 0) {
+        RowArgs a{X, ldx, N, D, u1, z, w, zeta2, dw, scale, family, nullptr, nullptr, nullptr, (double*)ws};
+        P = run_rows<OP_TAYLOR3>(a, st);
         if (P < 0) return P;
     }
     return finalize((const double*)ws, D, P, D, 0, 1.0, nullptr, nullptr, 0.0, out, st);

@@ -72,6 +72,20 @@ def glm_taylor2_rhs(obj, z, w, dw, u):
     return out
 
 
+def glm_taylor3_rhs(obj, z, w, dw, d1, d2):
+    """Third-order data-weight right-hand side of a WeightedGLMObjective: one pass for zeta2 = X d2,
+    one fused pass for the sum (see include/vittles_hip.h)."""
+    lib = dev.require_gpu()
+    zeta2 = gemv(obj.X, d2)
+    out = torch.empty(obj.D, dtype=torch.float64, device=obj.device)
+    ws = _workspace(obj.D, obj.device)
+    _lib.check(lib.vt_glm_taylor3_rhs(_lib.FAMILY[obj.family], obj.X.data_ptr(), dev.ld(obj.X), z.data_ptr(),
+                                      w.contiguous().data_ptr(), dw.contiguous().data_ptr(), zeta2.data_ptr(),
+                                      obj.scale, d1.contiguous().data_ptr(), obj.N, obj.D, out.data_ptr(),
+                                      ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_glm_taylor3_rhs")
+    return out
+
+
 _tn_ws_cache = {}
 
 

@@ -282,7 +282,7 @@ class ParametricSensitivityTaylorExpansion:
     hyper-parameter.  The reference expands an arbitrary estimating equation to arbitrary order
     with nested ``autograd.make_jvp`` calls; this build covers what has a fixed kernel shape
     (SURVEY.md section 8f, rank 4): **data weights of a registered ``WeightedGLMObjective``,
-    orders 1 and 2** (any order for the gaussian family, whose higher link derivatives vanish --
+    orders 1 to 3** (any order for the gaussian family, whose higher link derivatives vanish --
     the reference's own order-4 regression test runs), each order one streaming pass over X plus
     one Cholesky solve:
 
@@ -326,10 +326,10 @@ class ParametricSensitivityTaylorExpansion:
             raise ValueError('max_hyper_order must be >= 1.')
         if order < 1:
             raise ValueError('order must be at least one.')
-        if order > 2 and obj.family != 'gaussian':
+        if order > 3 and obj.family != 'gaussian':
             raise NotImplementedError(
-                'Taylor orders above 2 are built for the gaussian family only (its higher link '
-                'derivatives vanish); other families stop at order 2.')
+                'Taylor orders above 3 are built for the gaussian family only (its higher link '
+                'derivatives vanish); other families stop at order 3.')
         self._obj = obj
         self._input_val0 = deepcopy(input_val0)
         self._hyper_val0 = deepcopy(hyper_val0)
@@ -369,6 +369,8 @@ class ParametricSensitivityTaylorExpansion:
             vec = rows.gemv_t2(obj.X, self._r, dhyper)
         elif k == 2:
             vec = rows.glm_taylor2_rhs(obj, self._z, self._w, dhyper, input_derivs[0])
+        elif k == 3 and obj.family != 'gaussian':
+            vec = rows.glm_taylor3_rhs(obj, self._z, self._w, dhyper, input_derivs[0], input_derivs[1])
         else:
             # gaussian family: G is bilinear in (theta, w), so the order-k equation is
             # H d_k + k (d^2 G / d theta d w)[d_{k-1}, dw] = 0: one fused pass X^T (scale dw .* (X d_{k-1}))
