@@ -4,17 +4,26 @@
 Workload (BASELINE.json configs[1]): weighted logistic regression, N = 1,000,000 rows,
 D = 100, fp64, ridge prior 1: one "step" = all-N infinitesimal-jackknife sensitivities
 d theta-hat / d w  from device-resident (X, y, w, theta-hat) to device-resident S:
-    fused link+gradient+Hessian SYRK  ->  (all-reduce of H when row-sharded)
-    -> Cholesky -> TRSM operand pack -> MFMA multi-RHS TRSM  S = -H^{-1} (diag(r) X)^T
+    fused link+gradient+Hessian SYRK  ->  (all-reduce of [H | g] when row-sharded)
+    -> Cholesky + TRSM operand pack -> MFMA multi-RHS TRSM  S = -H^{-1} (diag(r) X)^T
 Metric: IJ sensitivities / second = (rows over all ranks) / (max-over-ranks step time).
-With --gpus N > 1 every rank holds its own N-row shard (weak scaling); the only
-collective is the RCCL all-reduce of the D x D partial Hessian.
+
+Multi-GPU (weak scaling: every rank holds its own --rows shard; the only data-path collective
+is the RCCL all-reduce of the (D*D + D)-double partial [H | g]):
+  * under torchrun (WORLD_SIZE set) this process is one rank;
+  * `python bench.py --gpus N` with N > 1 and no WORLD_SIZE starts N fresh rank processes
+    itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) BEFORE anything touches the GPU; the
+    parent never initialises HIP and never execs.  VITTLES_BENCH_BACKEND=gloo lets the ranks
+    share one card (rehearsal of the multi-rank code path on a one-GPU box).
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,59 +45,236 @@ def parse():
     p.add_argument("--dim", type=int, default=100)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-rows", type=int, default=1_000_000)
-    p.add_argument("--no-hvp", action="store_true", help="skip the HVP GB/s side measurement")
+    p.add_argument("--no-hvp", action="store_true", help="skip the HVP GB/s + CG side measurement (configs[3])")
     p.add_argument("--hvp-rows", type=int, default=100_000)
     p.add_argument("--hvp-dim", type=int, default=20_000)
+    p.add_argument("--cg-cpu-rows", type=int, default=4_000)
+    p.add_argument("--no-block", action="store_true", help="skip the block-sparse VI side measurement (configs[4])")
+    p.add_argument("--block-groups", type=int, default=10_000)
     return p.parse_args()
 
 
-def cpu_baseline(Xh, yh, wh, theta_h, prior, S_dev_rows, n_sample):
+# ------------------------------------------------------------------------------------------------
+# multi-rank launcher (parent process: no GPU call, no exec)
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(n):
+    """Start ``n`` fresh rank processes of this script and wait for them.  Runs before torch is
+    imported in this process; rank 0's stdout (the JSON line) is this process's stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VITTLES_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        try:
+            procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL))
+        except OSError as e:
+            for p in procs:
+                p.kill()
+            raise SystemExit("bench.py: could not start rank %d (%s); launch with "
+                             "`python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d` instead"
+                             % (r, e, n, n))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:          # one rank failed: the others would wait in a collective forever
+                    q.terminate()
+    if rc != 0:
+        raise SystemExit("bench.py: a rank exited with code %d (world of %d); the torchrun route is "
+                         "`python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
+                         "bench.py --gpus %d`" % (rc, n, n, n))
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (oracle = checker and reported baseline only; never on the product path)
+# ------------------------------------------------------------------------------------------------
+def blas_threads():
+    try:
+        import threadpoolctl
+        infos = threadpoolctl.threadpool_info()
+        return int(max([i.get("num_threads", 1) for i in infos if i.get("user_api") == "blas"] or [1]))
+    except Exception:
+        return 1
+
+
+def cpu_baseline(Xh, yh, wh, theta_h, prior, n_sample):
     """Time the oracle (CPU restatement: NumPy Hessian + the reference's LAPACK calls
     cho_factor/cho_solve with nrhs = N) on a bounded sample of the same workload and
     use it as the parity checker for the GPU result."""
     from oracle import glm
-    import threadpoolctl
     n = min(n_sample, Xh.shape[0])
     Xs, ys, ws = Xh[:n], yh[:n], wh[:n]
     glm.sensitivity("logistic", Xs[:20000], ys[:20000], theta_h, ws[:20000], prior=prior)   # warm-up
     t0 = time.perf_counter()
     H, jac0, S = glm.sensitivity("logistic", Xs, ys, theta_h, ws, prior=prior)
     dt = time.perf_counter() - t0
-    threads = 1
-    try:
-        infos = threadpoolctl.threadpool_info()
-        threads = max([i.get("num_threads", 1) for i in infos if i.get("user_api") == "blas"] or [1])
-    except Exception:
-        pass
-    return dict(value=n / dt, unit="sensitivities/s", cores=int(threads), kind="port",
+    return dict(value=n / dt, unit="sensitivities/s", cores=blas_threads(), os_cpu_count=os.cpu_count(),
+                kind="port",
                 sample="oracle.glm.sensitivity (NumPy X^T D X + scipy cho_factor/cho_solve, nrhs=N) on the first "
                        "%d rows of the same N x D workload, %.2f s" % (n, dt)), H, S
 
 
-def hvp_side_measurement(torch, device, n_rows, dim, reps=10):
-    """The metric's second figure: fused HVP kernel (BASELINE.json configs[3], D = 20k
-    ridge-logistic CG) in algorithmic GB/s = (8ND + 8N + 16D) / kernel time, HIP events on
-    the launch stream.  Runs after the timed region of the headline step, rank 0 only."""
-    from vittles_amd import rows
-    X = torch.randn((n_rows, dim), dtype=torch.float64, device=device)
-    d = torch.rand(n_rows, dtype=torch.float64, device=device)
-    v = torch.randn(dim, dtype=torch.float64, device=device)
+def hvp_cg_side_measurement(torch, device, n_rows, dim, cpu_rows, reps=10):
+    """BASELINE.json configs[3] (matrix-free CG, D = 20k ridge-logistic), after the timed region, N=1 only:
+    (i) the metric's second figure: fused HVP kernel in algorithmic GB/s = (8ND + 8N + 16D) / kernel
+        time, HIP events on the launch stream;
+    (ii) one CG solve H x = b (tol 1e-5, the reference's default) through the drop-in get_cg_solver
+        machinery, with its true residual;
+    (iii) CPU baseline B3 in the same run: scipy.sparse.linalg.cg(rtol=1e-5, atol=0) over a NumPy HVP
+        (solver_lib.py:91-97's LinearOperator) on the first ``cpu_rows`` rows."""
+    import vittles_amd as va
+    from vittles_amd import rows, cg
+    gen = torch.Generator(device=device)
+    gen.manual_seed(4321)
+    X = torch.randn((n_rows, dim), dtype=torch.float64, device=device, generator=gen)
+    theta_star = torch.randn(dim, dtype=torch.float64, device=device, generator=gen) / dim ** 0.5
+    y = (torch.rand(n_rows, dtype=torch.float64, device=device, generator=gen) < torch.sigmoid(X @ theta_star)).double()
+    w = torch.ones(n_rows, dtype=torch.float64, device=device)
+    theta = 0.5 * theta_star
+    obj = va.WeightedGLMObjective(X, y, family="logistic", prior=1.0)
+    hvp = cg.GLMHessianVectorProduct(obj, theta, w)
+    v = torch.randn(dim, dtype=torch.float64, device=device, generator=gen)
     out = torch.empty(dim, dtype=torch.float64, device=device)
     for _ in range(3):
-        rows.glm_hvp(X, d, v, prior_scalar=1.0, out=out)
+        hvp.apply(v, out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        rows.glm_hvp(X, d, v, prior_scalar=1.0, out=out)
+        hvp.apply(v, out)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     nbytes = 8.0 * n_rows * dim + 8.0 * n_rows + 16.0 * dim
     gbs = nbytes / (ms * 1e-3) / 1e9
+    res_hvp = {"kernel": "k_rows_wide<OP_HVP> (K6 fused HVP)", "rows": n_rows, "dim": dim, "ms": ms,
+               "algorithmic_bytes": nbytes, "GBs": gbs, "peak_GBs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}
+
+    # (ii) CG: right-hand side = the cross-Hessian applied to a weight perturbation, X^T (r .* dw)
+    _, r, _ = rows.glm_link(obj, theta, w)
+    dw = torch.randn(n_rows, dtype=torch.float64, device=device, generator=gen)
+    b = rows.gemv_t2(X, r, dw)
+    tol = 1e-5
+    cg.cg_solve(lambda p, q: hvp.apply(p, q), b, tol=tol)          # warm-up
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        x, info, iters = cg.cg_solve(lambda p, q: hvp.apply(p, q), b, tol=tol)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    gpu_s = float(np.median(times))
+    resid = float(((hvp.apply(x) - b).norm() / b.norm()).item())
+
+    # (iii) CPU B3 on a bounded row sample (same D, same tolerance)
+    import scipy.sparse.linalg as spla
+    from oracle import glm
+    nc = min(cpu_rows, n_rows)
+    Xc = X[:nc].cpu().numpy()
+    yc = y[:nc].cpu().numpy()
+    wc = np.ones(nc)
+    th = theta.cpu().numpy()
+    _, l1, l2 = glm.link("logistic", Xc @ th, yc)
+    bc = Xc.T @ (l1 * dw[:nc].cpu().numpy())
+    n_mv = [0]
+
+    def mv(vv):
+        n_mv[0] += 1
+        return Xc.T @ (l2 * (Xc @ vv)) + vv
+    linop = spla.LinearOperator((dim, dim), mv)
+    t0 = time.perf_counter()
+    xc, cinfo = spla.cg(linop, bc, rtol=tol, atol=0.0)
+    cpu_s = time.perf_counter() - t0
+    cpu_iters = n_mv[0]
     del X
-    return {"kernel": "k_rows_wide<OP_HVP> (K6 fused HVP)", "rows": n_rows, "dim": dim, "ms": ms,
-            "algorithmic_bytes": nbytes, "GBs": gbs, "peak_GBs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}
+    res_cg = {"workload": "matrix-free CG, ridge-logistic D=%d, N=%d rows on the GPU (configs[3]), tol=%g" % (dim, n_rows, tol),
+              "gpu_ms": gpu_s * 1e3, "gpu_iterations": int(iters), "gpu_info": int(info),
+              "gpu_true_residual_rel": resid,
+              "gpu_row_iterations_per_s": n_rows * max(iters, 1) / gpu_s,
+              "cpu_baseline": {"kind": "port", "what": "scipy.sparse.linalg.cg(rtol=%g, atol=0) + NumPy HVP "
+                               "(X^T(d*(Xv)) + v) on the first %d rows, same D" % (tol, nc),
+                               "rows": nc, "ms": cpu_s * 1e3, "iterations": cpu_iters, "info": int(cinfo),
+                               "cores": blas_threads(), "os_cpu_count": os.cpu_count(),
+                               "row_iterations_per_s": nc * max(cpu_iters, 1) / cpu_s}}
+    res_cg["speedup_row_iterations"] = res_cg["gpu_row_iterations_per_s"] / res_cg["cpu_baseline"]["row_iterations_per_s"]
+    return res_hvp, res_cg
+
+
+def block_side_measurement(torch, G, ng=16, k=4):
+    """BASELINE.json configs[4] (hierarchical mean-field Gaussian VI, G groups): SparseBlockHessian
+    assembly + LinearResponseCovariances through the drop-in classes (host arrays in / out, like the
+    reference's API), and CPU baseline B4 in the same run: the oracle's restatement of the reference
+    loops (sparse_hessian_lib.py:93-102, 130-156) over a NumPy HVP + scipy.sparse.linalg.factorized
+    (SuperLU, solver_lib.py:48) + J @ solve(J^T) (lr_cov_lib.py:172)."""
+    import vittles_amd as va
+    from oracle import vi, block_hessian, lr_cov
+    X, y = vi.synth(G, ng, k, 0)
+    m = vi.HierGaussMFVI(X, y, G, ng, k, 2.0, 1.5, 0.5)
+    eta = m.optimum()
+    nm = 8
+    K = nm * k + k
+    J = np.zeros((K, m.d))
+    for g in range(nm):
+        for j in range(k):
+            J[g * k + j, 2 * k * g + j] = 1.0
+    for j in range(k):
+        J[nm * k + j, 2 * k * G + j] = 1.0
+
+    obj = va.HierGaussMFVIObjective(X, y, G, ng, k, 2.0, 1.5, 0.5)
+    sb = va.SparseBlockHessian(obj, obj.sparsity_array())
+
+    def gpu_all():
+        t0 = time.perf_counter()
+        H = sb.get_hessian(eta)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        lr = va.LinearResponseCovariances(obj, eta, validate_optimum=True, hessian_at_opt=H, grad_tol=1e-6)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        cov = lr.get_lr_covariance_from_jacobians(J, J)
+        t3 = time.perf_counter()
+        return (t1 - t0, t2 - t1, t3 - t2), H, cov
+    gpu_all()
+    runs = [gpu_all() for _ in range(3)]
+    tg = np.median(np.array([r[0] for r in runs]), axis=0)
+    Hg, cov_g = runs[-1][1], runs[-1][2]
+
+    t0 = time.perf_counter()
+    Hc = block_hessian.SparseBlockHessian(m.hvp, m.sparsity_array()).get_hessian(eta)
+    t1 = time.perf_counter()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # SparseEfficiencyWarning: COO -> CSC, as in the reference
+        lrc = lr_cov.LinearResponseCovariances(m.grad, None, eta, validate_optimum=True, hessian_at_opt=Hc,
+                                               grad_tol=1e-6)
+        t2 = time.perf_counter()
+        cov_c = lrc.get_lr_covariance_from_jacobians(J, J)
+    t3 = time.perf_counter()
+    dH = abs(Hg - Hc)
+    return {"workload": "hierarchical MF-Gaussian VI, G=%d groups x %d rows, k=%d (d=%d), %d moments (configs[4])"
+                        % (G, ng, k, m.d, K),
+            "gpu_ms": {"get_hessian_host_to_host": tg[0] * 1e3, "lr_setup_factor_validate": tg[1] * 1e3,
+                       "lr_covariance": tg[2] * 1e3, "total": float(tg.sum()) * 1e3},
+            "cpu_baseline": {"kind": "port", "what": "oracle SparseBlockHessian loops over a NumPy HVP + "
+                             "scipy.sparse.linalg.factorized (SuperLU) + J @ solve(J^T)",
+                             "ms": {"get_hessian": (t1 - t0) * 1e3, "lr_setup_factor_validate": (t2 - t1) * 1e3,
+                                    "lr_covariance": (t3 - t2) * 1e3, "total": (t3 - t0) * 1e3},
+                             "cores": 1, "os_cpu_count": os.cpu_count()},
+            "speedup_total": (t3 - t0) / float(tg.sum()),
+            "parity": {"hessian_max_rel_err": float(dH.max() / abs(Hc).max()), "nnz": [int(Hg.nnz), int(Hc.nnz)],
+                       "lr_cov_max_rel_err": float(np.abs(cov_g - cov_c).max() / np.abs(cov_c).max()),
+                       "tolerance": 1e-10}}
 
 
 def config1_side_measurement(torch):
@@ -106,7 +292,7 @@ def config1_side_measurement(torch):
     obj = va.WeightedGLMObjective(X, y, family="logistic", prior=1.0)
 
     def gpu():
-        obj._cache_key = None
+        obj.invalidate_cache()
         la = va.HyperparameterSensitivityLinearApproximation(obj, theta, w)
         return la.get_dopt_dhyper()
     gpu()
@@ -136,7 +322,7 @@ def config1_side_measurement(torch):
             "cpu_ad_baseline_ms": ad_ms, "cpu_ad_sens_per_s": N / (ad_ms * 1e-3),
             "cpu_ad_kind": "torch.func.hessian + jacrev(grad, 1) fp64 + scipy cho_factor/cho_solve (stand-in for "
                            "vittles+autograd, not installed)", "cpu_threads": torch.get_num_threads(),
-            "S_max_rel_err_gpu_vs_ad": err}
+            "os_cpu_count": os.cpu_count(), "S_max_rel_err_gpu_vs_ad": err}
 
 
 def note(msg):
@@ -145,8 +331,28 @@ def note(msg):
               file=sys.stderr, flush=True)
 
 
+def latest_traffic(N, D):
+    """HBM traffic of the dominant kernel: PMC counters can only be collected under rocprofv3
+    (separate --pmc passes), so the per-launch figure measured for this exact workload is read from
+    the newest profiles/rNN_traffic.json and reported as null for any other shape."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(path))
+            if tj["workload"] == {"rows": N, "dim": D}:
+                k = tj["k_trsm_rows_small"]
+                return k["hbm_bytes_per_launch"], "%s (%s)" % (os.path.relpath(path, ROOT),
+                                                               tj.get("command", "rocprofv3 --pmc passes, see file"))
+        except Exception:
+            continue
+    return None, None
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)          # parent: never touches the GPU
+        return
+
     import torch
     import torch.distributed as dist
 
@@ -158,7 +364,11 @@ def main():
     # one rank per GPU; VITTLES_BENCH_BACKEND=gloo lets several ranks share one card to
     # rehearse the multi-rank code path on a one-GPU box (RCCL refuses duplicate devices)
     backend = os.environ.get("VITTLES_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if world > ndev and backend == "nccl":
+        raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible; RCCL needs one GPU per rank "
+                         "(VITTLES_BENCH_BACKEND=gloo rehearses the multi-rank path on one card)" % (world, ndev))
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     group = None
@@ -169,11 +379,11 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
+    coll_dev = device if backend == "nccl" else "cpu"
 
     note("process group up")
     import vittles_amd as va
     from vittles_amd.linalg import DeviceCholesky
-    from vittles_amd import _lib, device as dev
 
     N, D = args.rows, args.dim
     prior = 1.0
@@ -192,11 +402,15 @@ def main():
     grad_norm = float(obj.fused(theta.clone(), w)["g"].norm())
     note("theta-hat found, |g| = %.2e" % grad_norm)
 
-    lib = _lib.load()
     S = torch.empty((N, D), dtype=torch.float64, device=device)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-           torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
+    nev = 6
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nev)] for _ in range(args.steps)]
+    cur = [None]
+
+    def hook(name):          # events around the all-reduce inside obj.fused (timed steps only)
+        if cur[0] is not None:
+            ev[cur[0]][4 if name == "allreduce_begin" else 5].record()
+    obj.stage_hook = hook if world > 1 else None
 
     # potrf's LAPACK-style info of every step is read on the host inside the timed region, one
     # step late (pinned buffer + event), so the check never drains the stream
@@ -208,7 +422,8 @@ def main():
         DeviceCholesky.raise_for_info(int(info_host[i]))
 
     def step(i=None):
-        obj._cache_key = None               # no cached pass: every step streams X
+        obj.invalidate_cache()              # no cached pass: every step streams X
+        cur[0] = i
         if i is not None:
             ev[i][0].record()
         out = obj.fused(theta, w)           # K0+K1+K3 (+ all-reduce)
@@ -232,10 +447,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Cold figure (disclosed, never `value`): the first 20 passes after set-up, before the clock ramp.
+    step()
+    barrier()
+    t_cold = time.perf_counter()
+    for _ in range(20):
+        step()
+    barrier()
+    cold_ms = (time.perf_counter() - t_cold) / 20 * 1e3
+
     # Clock ramp (set-up, untimed): the shader clock needs ~50 ms of load to reach its sustained value,
     # so the pipeline runs for 0.2 s before the W warm-up steps -- a short --steps run then measures the
     # same sustained rate as a long one.  Every rank runs the same number of passes (collectives match).
-    barrier()
     t_ramp = time.perf_counter()
     n_ramp = 0
     while n_ramp < 2000:
@@ -243,8 +466,7 @@ def main():
             step()
         n_ramp += 25
         torch.cuda.synchronize()
-        go_on = torch.tensor([1.0 if time.perf_counter() - t_ramp < 0.2 else 0.0], dtype=torch.float64,
-                             device=device if backend == "nccl" else "cpu")
+        go_on = torch.tensor([1.0 if time.perf_counter() - t_ramp < 0.2 else 0.0], dtype=torch.float64, device=coll_dev)
         if world > 1:
             dist.all_reduce(go_on, op=dist.ReduceOp.MIN)
         if float(go_on.item()) == 0.0:
@@ -258,33 +480,34 @@ def main():
         out = step(i)
     check_info(args.steps - 1)
     barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    dt_local = time.perf_counter() - t0
+    cur[0] = None
+    per_rank = [dt_local]
+    seen = 1
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        tl = torch.tensor([dt_local], dtype=torch.float64, device=coll_dev)
+        allt = [torch.zeros_like(tl) for _ in range(world)]
+        dist.all_gather(allt, tl)
+        per_rank = [float(t.item()) for t in allt]
+        ones = torch.ones(1, dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(ones)
+        seen = int(round(float(ones.item())))
+    dt = max(per_rank)          # MAX over ranks
 
     ms_hess = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     ms_chol = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     ms_trsm = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+    ms_ar = float(np.mean([e[4].elapsed_time(e[5]) for e in ev])) if world > 1 else 0.0
 
     if rank == 0:
-        # HBM traffic of the dominant kernel: PMC counters can only be collected under rocprofv3
-        # (separate --pmc passes), so the per-launch figure measured for this exact workload is
-        # read from profiles/ and reported as null for any other shape.
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj["workload"] == {"rows": N, "dim": D}:
-                traffic = tj["k_trsm_rows_small"]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        traffic, traffic_source = latest_traffic(N, D)
         ms_per_step = dt / args.steps * 1e3
         value = world * N / (dt / args.steps)
         # dominant kernel: the MFMA TRSM (algorithmic flops 2 D^2 N, bytes 16 N D + 8 N)
         trsm_flops = 2.0 * D * D * N
         trsm_tflops = trsm_flops / (ms_trsm * 1e-3) / 1e12
         syrk_flops = float(N) * D * (D + 1)
+        ms_syrk = ms_hess - ms_ar          # the fused-pass stage minus the collective inside it
         result = {
             "metric": "IJ sensitivities/sec (all-N dtheta/dw) at N=1M,D=100",
             "value": value, "unit": "sensitivities/s", "n_gpus": world, "steps": args.steps,
@@ -293,39 +516,54 @@ def main():
             "config": {"workload": "weighted logistic regression N=%d D=%d fp64 per GPU "
                                    "(Hessian SYRK + multi-RHS TRSM), ridge prior 1" % (N, D),
                        "rows_per_gpu": N, "dim": D, "parallelism": "row-sharded dp%d" % world,
+                       "backend": backend if world > 1 else None,
                        "grad_norm_at_theta_hat": grad_norm},
+            "clock_ramp_steps": n_ramp + 21, "cold_ms_per_step": cold_ms,
+            "rccl_ranks_seen": seen, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
             "roofline": {"bound": "mfma", "kernel": "k_trsm_rows_small (K2+K5 sens TRSM)",
                          "achieved": trsm_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": trsm_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes": 16.0 * N * D + 8.0 * N, "algorithmic_flops": trsm_flops,
                          "ms": ms_trsm,
                          "hbm_GBs": (16.0 * N * D + 8.0 * N) / (ms_trsm * 1e-3) / 1e9},
-            "stages_ms": {"fused_link_grad_hessian": ms_hess, "cholesky_pack": ms_chol, "sens_trsm": ms_trsm},
-            "syrk": {"TFLOPs_triangle": syrk_flops / (ms_hess * 1e-3) / 1e12,
-                     "TFLOPs_full_square": 2.0 * N * D * D / (ms_hess * 1e-3) / 1e12,
-                     "hbm_GBs": (8.0 * N * D + 24.0 * N) / (ms_hess * 1e-3) / 1e9},
+            "stages_ms": {"fused_link_grad_hessian": ms_syrk, "all_reduce_H_g": ms_ar,
+                          "cholesky_pack": ms_chol, "sens_trsm": ms_trsm},
+            "syrk": {"TFLOPs_triangle": syrk_flops / (ms_syrk * 1e-3) / 1e12,
+                     "TFLOPs_full_square": 2.0 * N * D * D / (ms_syrk * 1e-3) / 1e12,
+                     "frac_of_peak_triangle": syrk_flops / (ms_syrk * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                     "hbm_GBs": (8.0 * N * D + 24.0 * N) / (ms_syrk * 1e-3) / 1e9},
         }
-        if not args.no_hvp and world == 1:   # side measurements run at N=1 only: no rank waits on rank 0
-            result["hvp"] = hvp_side_measurement(torch, device, args.hvp_rows, args.hvp_dim)
-        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 at N=1 only
-            n_s = min(args.cpu_rows, N)
-            Xh = X[:n_s].cpu().numpy()
-            yh = y[:n_s].cpu().numpy()
-            wh = w[:n_s].cpu().numpy()
-            theta_h = theta.cpu().numpy()
-            base, H_cpu, S_cpu = cpu_baseline(Xh, yh, wh, theta_h, prior, None, n_s)
-            result["cpu_baseline"] = base
-            if n_s == N and world == 1:
-                # same rows on both sides -> full parity check of H and S
-                Hg = out["H"].cpu().numpy()
-                Sg = S.cpu().numpy()
-                result["parity"] = {
-                    "H_max_rel_err": float(np.abs(Hg - H_cpu).max() / np.abs(H_cpu).max()),
-                    "S_max_rel_err": float(np.abs(Sg.T - S_cpu).max() / np.abs(S_cpu).max()),
-                    "rows_checked": int(N), "tolerance": 1e-10}
-            result["speedup_vs_cpu_baseline"] = value / base["value"]
-            result["config1"] = config1_side_measurement(torch)
-        print(json.dumps(result))
+        if world == 1:   # side measurements and CPU legs run at N=1 only: no rank waits on rank 0
+            if not args.no_cpu_baseline:
+                n_s = min(args.cpu_rows, N)
+                Xh = X[:n_s].cpu().numpy()
+                yh = y[:n_s].cpu().numpy()
+                wh = w[:n_s].cpu().numpy()
+                theta_h = theta.cpu().numpy()
+                base, H_cpu, S_cpu = cpu_baseline(Xh, yh, wh, theta_h, prior, n_s)
+                result["cpu_baseline"] = base
+                if n_s == N:
+                    # same rows on both sides -> full parity check of H and S
+                    Hg = out["H"].cpu().numpy()
+                    Sg = S.cpu().numpy()
+                    result["parity"] = {
+                        "H_max_rel_err": float(np.abs(Hg - H_cpu).max() / np.abs(H_cpu).max()),
+                        "S_max_rel_err": float(np.abs(Sg.T - S_cpu).max() / np.abs(S_cpu).max()),
+                        "rows_checked": int(N), "tolerance": 1e-10}
+                    del Sg
+                del Xh, H_cpu, S_cpu
+                result["speedup_vs_cpu_baseline"] = value / base["value"]
+                result["config1"] = config1_side_measurement(torch)
+            del S, X
+            torch.cuda.empty_cache()
+            if not args.no_hvp:
+                result["hvp"], result["cg"] = hvp_cg_side_measurement(torch, device, args.hvp_rows, args.hvp_dim,
+                                                                      args.cg_cpu_rows)
+                torch.cuda.empty_cache()
+            if not args.no_block:
+                result["block"] = block_side_measurement(torch, args.block_groups)
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -56,6 +56,40 @@ def test_cg_registered_hvp_matches_oracle(N, D, relerr):
     assert relerr(va.solver_lib.get_cg_solver(hvp, D, cg_opts={'tol': 1e-13})(b), np.linalg.solve(H, b)) < 1e-10
 
 
+def test_cg_config4_d20000(relerr):
+    """BASELINE.json configs[3] at its full width: D = 20 000 ridge-logistic, matrix-free CG through the
+    wide-row fused HVP kernel (k_rows_wide), against the oracle's restatement of the same iteration over
+    a NumPy HVP (N kept at a few thousand rows so the oracle finishes in seconds)."""
+    import torch
+    import vittles_amd as va
+    from vittles_amd.cg import GLMHessianVectorProduct, cg_solve
+    from oracle import glm, solvers
+    N, D = 3000, 20000
+    X, y, w, _ = glm.synth(N, D, "logistic", seed=20)
+    rng = np.random.default_rng(2)
+    theta = rng.standard_normal(D) / np.sqrt(D)
+    w = rng.uniform(0.5, 1.5, N)
+    prior = 1.0
+    obj = va.WeightedGLMObjective(X, y, family="logistic", prior=prior)
+    hvp = GLMHessianVectorProduct(obj, theta, w)
+    _, l1, l2 = glm.link("logistic", X @ theta, y)
+    dvec = w * l2
+    mv = lambda u: X.T @ (dvec * (X @ u)) + prior * u            # NumPy HVP (B3's mat_times_vec)
+    v = rng.standard_normal(D)
+    assert relerr(hvp(v), mv(v)) < 1e-10
+    b = X.T @ (l1 * rng.standard_normal(N))                       # jac0 @ dw: a directional sensitivity solve
+    bd = torch.tensor(b, device="cuda")
+    for tol in (1e-5, 1e-12):
+        x_ref, info_ref, it_ref = solvers.cg_legacy(mv, b, tol=tol, return_iters=True)
+        xd, info, iters = cg_solve(lambda p, out: hvp.apply(p, out), bd, tol=tol)
+        assert info == info_ref == 0 and abs(iters - it_ref) <= 1, (tol, iters, it_ref)
+        assert relerr(xd.cpu().numpy(), x_ref) < max(1e-10, 50 * tol * 1e-3), (tol, relerr(xd.cpu().numpy(), x_ref))
+        x = va.solver_lib.get_cg_solver(hvp, D, cg_opts={'tol': tol})(b)
+        assert relerr(x, x_ref) < max(1e-10, 50 * tol * 1e-3)
+        # true residual of the device solution, by the oracle's HVP
+        assert np.linalg.norm(mv(x) - b) <= max(2 * tol, 1e-10) * np.linalg.norm(b)
+
+
 def test_cg_directional_sensitivity(relerr):
     """The CG configuration is a directional solve: d theta = -H^{-1} (jac0 @ dw)."""
     import torch

@@ -84,6 +84,14 @@ class WeightedGLMObjective(RegisteredObjective):
         self._ws = None
         self._cache_key = None
         self._cache = None
+        self.stage_hook = None      # optional callable(name): 'allreduce_begin' / 'allreduce_end' (bench timers)
+
+    def invalidate_cache(self):
+        """Forget the cached fused pass.  The cache key is (data_ptr, torch version counter) of
+        (theta, w): a tensor rewritten behind torch's back (a raw kernel, a DLPack alias) keeps
+        its key -- call this after such an update."""
+        self._cache_key = None
+        self._cache = None
 
     # ---- distributed plumbing ------------------------------------------------
     def _rank(self):
@@ -126,7 +134,11 @@ class WeightedGLMObjective(RegisteredObjective):
             self.y.data_ptr(), w.data_ptr(), dev.ptr(self.offset), self.scale, dev.ptr(prior),
             self.N, self.D, H.data_ptr(), self.D, g.data_ptr(), r.data_ptr(), d.data_ptr(),
             self._ws.data_ptr(), self._ws.numel() * 8, dev.stream_ptr()), "vt_glm_hessian")
+        if self.stage_hook is not None:
+            self.stage_hook("allreduce_begin")
         self._all_reduce(Hg)          # one RCCL message: D*D + D doubles
+        if self.stage_hook is not None:
+            self.stage_hook("allreduce_end")
         out = dict(H=H, g=g, r=r, d=d, theta=theta, w=w)
         self._cache_key, self._cache = key, out
         return out

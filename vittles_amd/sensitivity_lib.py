@@ -19,11 +19,11 @@ import numpy as np
 import torch
 
 from . import device as dev
-from . import solver_lib
+from . import sharding, solver_lib
 from .objectives import RegisteredObjective, LazyCrossHessian
 
 
-def get_linear_function(return_val0, arg_val0, dreturn_darg_rows):
+def get_linear_function(return_val0, arg_val0, dreturn_darg_rows, process_group=None):
     """Reference: ``get_linear_function`` (sensitivity_lib.py:18-82): a differentiable function
     that returns ``return_val0`` when evaluated at ``arg_val0`` and whose Jacobian is the
     pre-computed ``dreturn_darg``.  The reference registers an autograd primitive with
@@ -32,7 +32,10 @@ def get_linear_function(return_val0, arg_val0, dreturn_darg_rows):
     being one streaming pass over the device-resident Jacobian.
 
     ``dreturn_darg_rows``: the Jacobian TRANSPOSED, (len(arg), len(return)) row-major on the
-    device (how the sensitivity matrix is stored).  As in the reference the function must be
+    device (how the sensitivity matrix is stored).  ``process_group``: the argument is ROW-SHARDED
+    over the ranks of that group (each rank holds its slice of ``arg`` and the matching rows of the
+    Jacobian): the JVP ``J t = sum_ranks J_r t_r`` is all-reduced, the VJP ``g^T J_r`` is this
+    rank's slice of the gradient and needs no communication.  As in the reference the function must be
     evaluated at ``arg_val0`` (ValueError otherwise) and is only once differentiable."""
     from torch.autograd.function import once_differentiable
     from . import rows
@@ -60,7 +63,8 @@ def get_linear_function(return_val0, arg_val0, dreturn_darg_rows):
 
         @staticmethod
         def jvp(ctx, t):
-            return rows.gemv_t(dreturn_darg_rows, t.to(torch.float64).contiguous())   # J @ t
+            out = rows.gemv_t(dreturn_darg_rows, t.to(torch.float64).contiguous())    # J @ t
+            return sharding.all_reduce_sum(out, process_group)
 
     def get_return_par(arg_par):
         if isinstance(arg_par, torch.Tensor):
@@ -98,6 +102,10 @@ class EstimatingEquationLinearApproximation:
         self._hyper_ee_fun_jac = getattr(self._hyper_par_estimating_equation, "jacobian_hyper", None)
         self._hess_solver = hess_solver
         self._solution_tol = solution_tol
+        # a row-sharded registered objective (one rank per GPU, each holding a slice of the hyper-
+        # parameter = data weights): products that sum over the hyper axis are all-reduced
+        if not hasattr(self, '_process_group'):
+            self._process_group = getattr(getattr(estimating_equation, '_obj', None), 'process_group', None)
         self.set_location(input_val0, hyper_val0, estimating_equation_jac0,
                           validate_solution=validate_solution, solution_tol=solution_tol)
 
@@ -176,7 +184,9 @@ class EstimatingEquationLinearApproximation:
         delta = dev.to_device(new_hyper_par_value, devc) - dev.to_device(self._hyper_val0, devc)
         if delta.ndim != 1 or delta.shape[0] != self._sens_rows.shape[0]:
             raise ValueError('new_hyper_par_value has the wrong shape.')
-        out = rows.gemv_t(self._sens_rows, delta) + dev.to_device(self._input_val0, devc)
+        part = rows.gemv_t(self._sens_rows, delta)          # this rank's rows of S: a partial sum
+        sharding.all_reduce_sum(part, self._process_group)
+        out = part + dev.to_device(self._input_val0, devc)
         return dev.like_input(out, self._input_val0)
 
     def predict_input_par_from_hyper_par_batch(self, new_hyper_par_values):
@@ -193,15 +203,22 @@ class EstimatingEquationLinearApproximation:
         W = dev.to_device(new_hyper_par_values, devc)
         if W.ndim != 2 or W.shape[0] != self._sens_rows.shape[0]:
             raise ValueError('new_hyper_par_values must have shape (len(hyper_par), K).')
-        bias = dev.to_device(self._input_val0, devc) - \
-            rows.gemv_t(self._sens_rows, dev.to_device(self._hyper_val0, devc))
-        out = rows.gemm_tn(W, self._sens_rows, bias=bias)        # (K, D) row-major
+        sw0 = rows.gemv_t(self._sens_rows, dev.to_device(self._hyper_val0, devc))
+        if self._process_group is None:
+            bias = dev.to_device(self._input_val0, devc) - sw0
+            out = rows.gemm_tn(W, self._sens_rows, bias=bias)        # (K, D) row-major
+        else:
+            # row-sharded: S^T W - S^T w0 summed over the ranks' rows, input0 added once
+            out = rows.gemm_tn(W, self._sens_rows, bias=-sw0)
+            sharding.all_reduce_sum(out, self._process_group)
+            out += dev.to_device(self._input_val0, devc)
         return dev.like_input(out.t(), self._input_val0)
 
     def get_input_par_function(self):
         """Reference :249-254: the optimum as a differentiable function of the hyper-parameter
         (a ``torch.autograd.Function`` here instead of an autograd primitive)."""
-        return get_linear_function(self._input_val0, self._hyper_val0, self._sens_rows)
+        return get_linear_function(self._input_val0, self._hyper_val0, self._sens_rows,
+                                   process_group=self._process_group)
 
 
 class HyperparameterSensitivityLinearApproximation(EstimatingEquationLinearApproximation):
@@ -211,6 +228,7 @@ class HyperparameterSensitivityLinearApproximation(EstimatingEquationLinearAppro
                  validate_optimum=False, hessian_at_opt=None, cross_hess_at_opt=None,
                  hyper_par_objective_fun=None, grad_tol=1e-8):
         self._objective_fun = objective_fun
+        self._process_group = getattr(objective_fun, 'process_group', None)
         registered = isinstance(objective_fun, RegisteredObjective)
         if not registered and not callable(objective_fun):
             raise TypeError('objective_fun must be callable.')
