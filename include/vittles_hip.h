@@ -51,6 +51,7 @@ extern "C" {
 #define VT_ERR_WORKSPACE      -3   /* ws_bytes too small */
 #define VT_ERR_HIP            -4   /* a HIP runtime call failed */
 #define VT_ERR_NO_DEVICE      -5
+#define VT_ERR_SCRATCH_LIMIT  -6   /* input larger than the static scratch of vt_glm_hvp_noalloc */
 
 #define VT_FAMILY_LOGISTIC 0
 #define VT_FAMILY_POISSON  1
@@ -157,6 +158,21 @@ int    vt_glm_grad(int family, const double* X_dev, int64_t ldx, const double* t
 int    vt_glm_hvp(const double* X_dev, int64_t ldx, const double* d_dev, const double* prior_dev,
                   double prior_scalar, const double* v_dev, int64_t N, int D, double* out_dev,
                   void* ws_dev, size_t ws_bytes, void* stream);
+
+/* vt_glm_hvp without a workspace argument, for callers that cannot allocate.
+ * No counterpart in the reference: this entry point exists for callers that must not call hipMalloc
+ * (code under HIP graph capture, tight serving loops around the CG iteration, harnesses that forbid
+ * allocation) and so cannot size and hand over `ws` either.  Same kernels and bit-identical results as
+ * vt_glm_hvp; the per-workgroup partial slabs live in a static device array of VT_NOALLOC_SCRATCH_BYTES
+ * (41.9 MB, held by every GPU the library runs on until the process ends), enough for every D the row
+ * kernels take (D <= VT_ROWS_D_MAX on a GPU of <= 256 CUs); anything larger returns
+ * VT_ERR_SCRATCH_LIMIT.  Calls no hipMalloc / hipFree.  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (two streams) race.  The first call on a device resolves the array's
+ * address (hipGetSymbolAddress): make it once outside any graph capture. */
+#define VT_NOALLOC_SCRATCH_BYTES ((size_t)256 * (VT_ROWS_D_MAX + 1) * 8)
+int    vt_glm_hvp_noalloc(const double* X_dev, int64_t ldx, const double* d_dev, const double* prior_dev,
+                          double prior_scalar, const double* v_dev, int64_t N, int D, double* out_dev,
+                          void* stream);
 
 /* K9: out (D,) = A^T u for a row-major (N, D) A.
  * Replaces: `self._sens_mat @ (new_hyper_par_value - self._hyper_val0)`

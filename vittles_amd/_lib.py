@@ -45,6 +45,7 @@ SIGNATURES = {
     "vt_glm_grad": (c_int, [c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_ptr, c_i64, c_int,
                             c_ptr, c_ptr, c_ptr, c_ptr, c_size_t, c_ptr]),
     "vt_glm_hvp": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_dbl, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size_t, c_ptr]),
+    "vt_glm_hvp_noalloc": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_dbl, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "vt_gemv_t": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size_t, c_ptr]),
     "vt_gemv": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size_t, c_ptr]),
     "vt_gemv_t2": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size_t, c_ptr]),

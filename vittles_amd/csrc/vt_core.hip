@@ -11,6 +11,8 @@ extern "C" const char* vt_error_string(int code) {
         case VT_ERR_WORKSPACE: return "workspace missing or too small (see *_workspace_bytes)";
         case VT_ERR_HIP: return "a HIP runtime call or kernel launch failed";
         case VT_ERR_NO_DEVICE: return "no HIP device";
+        case VT_ERR_SCRATCH_LIMIT:
+            return "input exceeds the static scratch of the no-alloc entry point (D <= 20448 on a GPU of <= 256 CUs)";
         default: return code > 0 ? "LAPACK-style info > 0" : "unknown error";
     }
 }

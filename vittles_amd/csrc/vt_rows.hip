@@ -15,6 +15,7 @@
 //   the user's `mat_times_vec` HVP handed to get_cg_solver  vittles/solver_lib.py:70-98
 //   `self._sens_mat @ (new_hyper - hyper0)`            vittles/sensitivity_lib.py:245-247
 #include "vt_common.h"
+#include <mutex>
 
 namespace {
 
@@ -656,4 +657,64 @@ extern "C" int vt_glm_value(int family, const double* X, int64_t ldx, const doub
     }
     // value = scale * sum_n w_n ell_n   (the prior term is added by the caller)
     return finalize((const double*)ws, D, P, 1, D, scale, nullptr, nullptr, 0.0, value_out, st);
+}
+
+// ---- the one entry point that allocates nothing (no counterpart in the reference) -----------------
+// vt_glm_hvp for callers that cannot hand over (or allocate) a workspace: code under HIP graph capture,
+// tight serving loops, harnesses that forbid hipMalloc.  The per-workgroup partial slabs that vt_glm_hvp
+// keeps in the caller's `ws` live in a file-scope device array instead.  Its size covers every D the row
+// kernels take: D <= 4096 uses at most 4 workgroups per CU of 256 CUs (1024 slabs of D + 1 doubles),
+// 4096 < D <= 20448 one 512-thread team per CU (256 slabs): 256 * 20449 doubles = 41.9 MB per GPU, held
+// until the process ends.  Every call on a GPU shares that GPU's array (calls that overlap on one GPU race);
+// nothing in it has to start at zero: every slab the finalize kernel reads is fully written by the row
+// kernel of the same call.
+namespace {
+constexpr size_t kScratchDoubles = (size_t)256 * (kWideDMax + 1);
+static __device__ __align__(256) double scratch[kScratchDoubles];
+
+constexpr int kMaxDevices = 64;
+double* g_scratch_ptr[kMaxDevices];          // per device: the address of ITS copy of `scratch`
+std::mutex g_scratch_mutex;
+
+// `scratch` is a host-side stand-in in host code, not a device address: resolve it once per device, with
+// that device current, and use the resolved pointer everywhere.
+int scratch_for_current_device(double** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return VT_ERR_HIP;
+    if (dev < 0 || dev >= kMaxDevices) return VT_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        double* ptr = nullptr;
+        if (hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) return VT_ERR_HIP;
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return VT_OK;
+}
+}  // namespace
+
+static_assert(kScratchDoubles * sizeof(double) == VT_NOALLOC_SCRATCH_BYTES, "header states the scratch size");
+
+extern "C" int vt_glm_hvp_noalloc(const double* X, int64_t ldx, const double* d, const double* prior,
+                                  double prior_scalar, const double* v, int64_t N, int D, double* out,
+                                  void* stream) {
+    if ((!X && N > 0) || N < 0 || D < 1 || ldx < D) return VT_ERR_BAD_ARG;
+    if (!v || !out || (N > 0 && !d)) return VT_ERR_BAD_ARG;
+    if (D > kWideDMax) return VT_ERR_SCRATCH_LIMIT;
+    // slabs one call can write: the grid cap of the kernel family that takes this D
+    size_t slabs = D > 4096 ? (size_t)num_cu() : (size_t)max_grid();
+    if (slabs * (size_t)(D + 1) > kScratchDoubles) return VT_ERR_SCRATCH_LIMIT;
+    double* ptr = nullptr;
+    int rc = scratch_for_current_device(&ptr);
+    if (rc != VT_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    int P = 0;
+    if (N > 0) {
+        RowArgs a{X, ldx, N, D, v, nullptr, nullptr, nullptr, d, 1.0, 0, nullptr, nullptr, nullptr, ptr};
+        P = run_rows<OP_HVP>(a, st);
+        if (P < 0) return P;
+        if ((size_t)P > slabs) return VT_ERR_HIP;   // cannot happen: run_rows caps its grid at `slabs`
+    }
+    bool has_prior = prior != nullptr || prior_scalar != 0.0;
+    return finalize(ptr, D, P, D, 0, 1.0, prior, has_prior ? v : nullptr, prior_scalar, out, st);
 }
