@@ -18,6 +18,7 @@
 #include "vt_common.h"
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 #ifndef VT_ABL
 #define VT_ABL 0   // dev-only compile-time ablation mask (tools/build_abl.cmd)
 #endif
@@ -40,7 +41,6 @@ struct HessArgs {
     double* part;       // [gridDim.x][L] partial slabs, L = NBT*256 + NB*16
     double* wave_part;  // [gridDim.x][4][NBT*256] per-wave slabs
     double* sink;       // 1024 doubles nobody reads
-    int ablate;         // dev only (VT_HESS_ABLATE): 1 = no MFMA phase, 2 = no global loads
 };
 
 // Loads are UNCONDITIONAL with clamped row / column indices (a per-element
@@ -279,19 +279,116 @@ constexpr int kTileMinRows = 4096;
 
 __host__ __device__ constexpr int tile_rs(int NB) { return (NB & 1) ? 16 * NB : 16 * NB + 16; }
 __host__ __device__ constexpr int tile_rows(int NB) { return NB <= 7 ? 48 : 36; }   // 3 buffers must fit 160 KB
-// blocks in bottom-row-first order; consecutive runs of that order go to the NQ owners
+// Row strips of the LAST block row.  When D mod 16 is 1..8 only the first 4 (or 8) rows of block row NB-1
+// are real, and its blocks are computed by NS = 1 (or 2) v_mfma_f64_4x4x4_4b products of 16 pipe cycles each
+// instead of one 64-cycle 16x16x4 product: the four 4x4 blocks of that instruction take the SAME 4 rows as A
+// (lane l: X[k = l>>4][16(NB-1) + 4s + (l&3)]) against the four 4-column groups of the ordinary B operand
+// (lane l: d_k X[k][16j + (l&15)]), and their result lane L holds row 4s + (L>>4), column L&15 of the block:
+// exactly register s of the 16x16 accumulator layout.  Measured (tools/micro/mfma_f64_4x4.hip): 16-17 pipe
+// cycles, mixes with the 16x16x4 form at no cost.  NS = 0: block row NB-1 is an ordinary one.
+__host__ __device__ constexpr int tile_strips(int D) { return (D % 16 >= 1 && D % 16 <= 8) ? (D % 16 + 3) / 4 : 0; }
+__host__ __device__ constexpr int blk_cost(int NB, int NS, int i) { return (NS > 0 && i == NB - 1) ? 16 * NS : 64; }
+// Block (i, j) of the lower block triangle -> bit / accumulator order.
 __host__ __device__ constexpr int blk_ord(int NB, int i, int j) { return (NB * (NB + 1) - (i + 1) * (i + 2)) / 2 + j; }
-__host__ __device__ constexpr int blk_owner(int NB, int NQ, int i, int j) {
-    return blk_ord(NB, i, j) * NQ / (NB * (NB + 1) / 2);
+// Which SIMD (quarter) owns which block.  What a quarter pays per k-step is the MFMA pipe cycles of its blocks
+// plus one v_mul_f64 (d_n * x: the B operand) per distinct block COLUMN it touches, so: whole columns are dealt
+// out longest-first to the least loaded quarter, then single blocks move from the most loaded quarter to
+// another one for as long as that lowers the maximum.  D = 100 (7 block rows, last one a 4-row strip):
+// {6 full | 5 full + 3 strips | 5 full + 2 strips | 5 full + 2 strips} = 384 / 368 / 352 / 352 pipe cycles with
+// 1 / 3 / 2 / 2 multiplies (bottom-row-first runs of equal cost: 7 / 6 / 5 / 3 multiplies).
+struct OwnTab { int own[8][8]; };
+constexpr int kMulCycles = 5;
+__host__ __device__ constexpr int own_load(const OwnTab& t, int NB, int NS, int q) {
+    int pipe = 0, cols = 0;
+    for (int j = 0; j < NB; ++j) {
+        bool any = false;
+        for (int i = j; i < NB; ++i)
+            if (t.own[i][j] == q) { pipe += blk_cost(NB, NS, i); any = true; }
+        cols += any ? 1 : 0;
+    }
+    return pipe + kMulCycles * cols;
 }
-// does quarter Q own a block in block row or block column b?
-__host__ __device__ constexpr bool blk_needed(int NB, int NQ, int Q, int b) {
+__host__ __device__ constexpr OwnTab make_own(int NB, int NS, int NQ) {
+    OwnTab t{};
+    int colcost[8] = {}, loads[8] = {};
+    bool used[8] = {};
+    for (int j = 0; j < NB; ++j)
+        for (int i = j; i < NB; ++i) colcost[j] += blk_cost(NB, NS, i);
+    for (int n = 0; n < NB; ++n) {
+        int jb = -1, qb = 0;
+        for (int j = 0; j < NB; ++j)
+            if (!used[j] && (jb < 0 || colcost[j] > colcost[jb])) jb = j;
+        for (int q = 1; q < NQ; ++q)
+            if (loads[q] < loads[qb]) qb = q;
+        used[jb] = true;
+        loads[qb] += colcost[jb];
+        for (int i = jb; i < NB; ++i) t.own[i][jb] = qb;
+    }
+    for (int it = 0; it < 64; ++it) {
+        int L[8] = {}, qmax = 0;
+        long long mx = 0, sq = 0;
+        for (int q = 0; q < NQ; ++q) {
+            L[q] = own_load(t, NB, NS, q);
+            if (L[q] > L[qmax]) qmax = q;
+            sq += (long long)L[q] * L[q];
+        }
+        mx = L[qmax];
+        long long bmx = mx, bsq = sq;
+        int bi = -1, bj = -1, bq = -1;
+        for (int j = 0; j < NB; ++j)
+            for (int i = j; i < NB; ++i) {
+                if (t.own[i][j] != qmax) continue;
+                for (int q = 0; q < NQ; ++q) {
+                    if (q == qmax) continue;
+                    t.own[i][j] = q;
+                    long long m2 = 0, s2 = 0;
+                    for (int k = 0; k < NQ; ++k) {
+                        const long long l = own_load(t, NB, NS, k);
+                        m2 = l > m2 ? l : m2;
+                        s2 += l * l;
+                    }
+                    t.own[i][j] = qmax;
+                    if (m2 < bmx || (m2 == bmx && s2 < bsq)) { bmx = m2; bsq = s2; bi = i; bj = j; bq = q; }
+                }
+            }
+        if (bi < 0) break;
+        t.own[bi][bj] = bq;
+    }
+    return t;
+}
+// The masks the kernel tests (compile-time constants): OWN bit blk_ord(i, j): quarter Q owns block (i, j);
+// NEED bit b: it reads the ordinary operand of column block b (A of a full block, or B); COLS bit j: it owns a
+// block in block column j (needs the scaled B operand d * x_j); strip: it owns a block of the strip row.
+__host__ __device__ constexpr unsigned long long own_mask(const OwnTab& t, int NB, int Q) {
+    unsigned long long m = 0;
     for (int i = 0; i < NB; ++i)
         for (int j = 0; j <= i; ++j)
-            if (blk_owner(NB, NQ, i, j) == Q && (i == b || j == b)) return true;
+            if (t.own[i][j] == Q) m |= 1ull << blk_ord(NB, i, j);
+    return m;
+}
+__host__ __device__ constexpr unsigned need_mask(const OwnTab& t, int NB, int NS, int Q) {
+    unsigned m = 0;
+    for (int i = 0; i < NB; ++i)
+        for (int j = 0; j <= i; ++j)
+            if (t.own[i][j] == Q) {
+                m |= 1u << j;
+                if (!(NS > 0 && i == NB - 1)) m |= 1u << i;
+            }
+    return m;
+}
+__host__ __device__ constexpr unsigned cols_mask(const OwnTab& t, int NB, int Q) {
+    unsigned m = 0;
+    for (int i = 0; i < NB; ++i)
+        for (int j = 0; j <= i; ++j)
+            if (t.own[i][j] == Q) m |= 1u << j;
+    return m;
+}
+__host__ __device__ constexpr bool strip_needed(const OwnTab& t, int NB, int NS, int Q) {
+    if (NS == 0) return false;
+    for (int j = 0; j < NB; ++j)
+        if (t.own[NB - 1][j] == Q) return true;
     return false;
 }
-__host__ __device__ constexpr int own_first(int NB, int NQ, int Q) { return (Q * (NB * (NB + 1) / 2) + NQ - 1) / NQ; }
 
 template <int NB>
 struct TileLds {   // offsets in doubles
@@ -301,21 +398,32 @@ struct TileLds {   // offsets in doubles
     static constexpr int kD = 3 * TR * RS;                // [3][TR]  d_n of the tile
     static constexpr int kTheta = kD + 3 * TR;            // [NB*16]
     static constexpr int kScratch = kTheta + NB * 16;     // [4 SIMDs][32]: z and w_n r_n of the duty wave's rows
-    static constexpr int kTotal = kScratch + 4 * 32;
+    static constexpr int kY = kScratch + 4 * 32;          // [3][TR] y_n, [3][TR] w_n, [3][TR] offset_n of the tiles
+    static constexpr int kW = kY + 3 * TR;
+    static constexpr int kOff = kW + 3 * TR;
+    static constexpr int kTotal = kOff + 3 * TR;
 };
 
-template <int NB, int FAM, bool HAS_OFF, int Q>
+template <int NB, int NS, int FAM, int Q>
 __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, int64_t mine) {
     using LY = TileLds<NB>;
     constexpr int NQ = kTileNQ, NK = kTileNK, RS = LY::RS, TR = LY::TR;
     constexpr int NBT = NB * (NB + 1) / 2;
-    constexpr int FIRST = own_first(NB, NQ, Q);
-    constexpr int NOWN = own_first(NB, NQ, Q + 1) - FIRST;
+    constexpr OwnTab TAB = make_own(NB, NS, NQ);
+    constexpr bool STRIP = strip_needed(TAB, NB, NS, Q);
+    // ownership as compile-time bit masks (bit blk_ord(i, j) / bit b / bit j): the unrolled loops below test
+    // plain constants -- left to fold blk_owner()'s own loops per iteration, the optimiser sometimes does not
+    constexpr unsigned long long OWN = own_mask(TAB, NB, Q);
+    constexpr int NOWN = __builtin_popcountll(OWN);
+    // accumulator slot of an owned block = its rank among the quarter's blocks
+    auto slot = [](int ord) constexpr { return __builtin_popcountll(OWN & ((1ull << ord) - 1ull)); };
+    constexpr unsigned NEED = need_mask(TAB, NB, NS, Q), COLS = cols_mask(TAB, NB, Q);
     constexpr int RPS = TR / 4;                        // rows a duty wave links (one wave per SIMD)
     constexpr int PASSES = (RPS + 3) / 4;
     constexpr int CH = RS / 2;                         // 16-byte chunks per LDS row
     constexpr int DMAH = (CH + 63) / 64;               // DMA instructions per row
     static_assert(TR % kTileWaves == 0 && TR % 4 == 0 && (TR / 4) % NK == 0, "tile shape");
+    static_assert(2 * RPS <= 64, "one DMA instruction moves a SIMD's per-row scalars");
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -326,7 +434,9 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
     // scalar stage of the link: lane t < RPS owns row RPS*simd + t
     const int trow = RPS * simd + (lane & 15);
     const bool tlane = lane < RPS;
+    const int trow_c = trow < TR ? trow : TR - 1;        // in-bounds LDS index for the other lanes
 
+    // accumulators: one f64x4 per owned block; a strip block only ever touches components 0..NS-1
     f64x4 acc[NOWN > 0 ? NOWN : 1];
 #pragma unroll
     for (int i = 0; i < NOWN; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
@@ -341,6 +451,10 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
     };
     // the RPS rows of my SIMD of tile k -> buffer `buf`.  One descriptor per row (SALU only):
     // lanes past the row's D doubles and rows past N read 0, and the only VGPR is 16 * chunk.
+    // The per-row scalars y, w (offset) of those rows ride along the same way, one dword per lane: NOTHING
+    // the FETCH wave loads has a VGPR destination, so no register hazard makes the compiler park it on
+    // s_waitcnt vmcnt(0) -- i.e. on the HBM latency of its own DMA -- before its MFMA k-steps (it did when
+    // y and w were buffer loads into registers: the allocator reused their registers inside the MFMA loop).
     auto dma = [&](int64_t k, int buf) {
         const int nrow = (VT_ABL & 2) ? 0 : tile_nrow(k);
         const int64_t rb = nrow > 0 ? tile_first_row(k) : 0;
@@ -357,11 +471,20 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (vt_ldsptr)(dst + 128 * h), 16, 16u * chunk, 0, 0, 0);
             }
         }
+        if (lane < 2 * RPS) {
+            const unsigned vo = 8u * (RPS * simd) + 4u * lane;
+            const int so = buf * TR + RPS * simd;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(tile_rsrc(a.y + rb, 8u * nrow), (vt_ldsptr)(lds + LY::kY + so), 4, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(tile_rsrc(a.w + rb, 8u * nrow), (vt_ldsptr)(lds + LY::kW + so), 4, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(tile_rsrc(a.offset + rb, a.offset ? 8u * nrow : 0u),
+                                                     (vt_ldsptr)(lds + LY::kOff + so), 4, vo, 0, 0, 0);
+        }
     };
     // k-steps [kfirst, kfirst + cnt) of the tile in `buf`.  ONE code path for all three roles, a real
     // loop with a wave-uniform trip count: when every role had its own unrolled copy, hipcc gave the
     // accumulators different registers on each path and moved all of them back (28 v_mov_b64 behind an
     // s_nop 15) every period.
+    const unsigned strip_lane = 8u * (unsigned)(c & 3) - 8u * (unsigned)c;   // byte offset: column c -> column c & 3
     auto mfma_part = [&](int buf, int kfirst, int cnt) {
         if (!(VT_ABL & 1)) {
             // The operand reads are inline asm: as compiler-visible LDS loads they make hipcc wait for the
@@ -374,27 +497,47 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
 #pragma nounroll
             for (int m = 0; m < cnt; ++m) {
                 double xa[8];
+                double xs[2] = {0.0, 0.0};
                 double dq;
                 asm volatile("ds_read_b64 %0, %1" : "=v"(dq) : "v"(da));
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    if (blk_needed(NB, NQ, Q, b))   // column blocks this quarter's products touch
+                    if ((NEED >> b) & 1)   // column blocks this quarter's products touch
                         asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xa[b]) : "v"(ta), "n"(128 * b));
                     else
                         xa[b] = 0.0;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dq), "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]));
-                if constexpr (NB > 4) asm volatile("" : "+v"(xa[4]));
-                if constexpr (NB > 5) asm volatile("" : "+v"(xa[5]));
-                if constexpr (NB > 6) asm volatile("" : "+v"(xa[6]));
-                if constexpr (NB > 7) asm volatile("" : "+v"(xa[7]));
+                if constexpr (STRIP) {
+                    const unsigned tas = ta + strip_lane;
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2)
+                        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xs[s2]) : "v"(tas), "n"(128 * (NB - 1) + 32 * s2));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dq));
+                // every operand is tied to a volatile asm BEHIND the wait (volatile asms keep their order)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    if ((NEED >> b) & 1) asm volatile("" : "+v"(xa[b]));
+                if constexpr (STRIP) {
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2) asm volatile("" : "+v"(xs[s2]));
+                }
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
+                    if (!((COLS >> j) & 1)) continue;
                     const double bj = dq * xa[j];
 #pragma unroll
                     for (int i = j; i < NB; ++i)
-                        if (blk_owner(NB, NQ, i, j) == Q)
-                            acc[blk_ord(NB, i, j) - FIRST] = mfma_f64(xa[i], bj, acc[blk_ord(NB, i, j) - FIRST]);
+                        if ((OWN >> blk_ord(NB, i, j)) & 1) {
+                            f64x4& ac = acc[slot(blk_ord(NB, i, j))];
+                            if (NS > 0 && i == NB - 1) {
+#pragma unroll
+                                for (int s2 = 0; s2 < NS; ++s2)
+                                    ac[s2] = __builtin_amdgcn_mfma_f64_4x4x4f64(xs[s2], bj, ac[s2], 0, 0, 0);
+                            } else {
+                                ac = mfma_f64(xa[i], bj, ac);
+                            }
+                        }
                 }
                 ta += 4 * RS * 8;
                 da += 4 * 8;
@@ -404,16 +547,6 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
         __builtin_amdgcn_sched_barrier(0);
     };
     // Link of the RPS rows [RPS*simd, RPS*(simd+1)) of tile k (in buffer `buf`).
-    double sy = 0.0, sw = 0.0, soff = 0.0;
-    auto load_scal = [&](int64_t k) {
-        const int nrow = tile_nrow(k);
-        const int64_t rb = nrow > 0 ? tile_first_row(k) : 0;
-        const unsigned ro = tlane ? 8u * trow : 0xfffffff0u;
-        sy = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tile_rsrc(a.y + rb, 8u * nrow), ro, 0, 0));
-        sw = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tile_rsrc(a.w + rb, 8u * nrow), ro, 0, 0));
-        if (HAS_OFF)
-            soff = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tile_rsrc(a.offset + rb, 8u * nrow), ro, 0, 0));
-    };
     auto link = [&](int64_t k, int buf) {
         const int nrow = tile_nrow(k);
         const int64_t rb = nrow > 0 ? tile_first_row(k) : 0;
@@ -434,8 +567,9 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
         }
         // stage 2: the scalar chain, one lane per row
         {
-            double z = zs[lane & 15];
-            if (HAS_OFF) z += soff;
+            const double sy = lds[LY::kY + buf * TR + trow_c];
+            const double sw = lds[LY::kW + buf * TR + trow_c];
+            double z = zs[lane & 15] + lds[LY::kOff + buf * TR + trow_c];
             double l1, l2;
             vt_link(FAM, z, sy, l1, l2);
             const bool rowok = tlane && trow < nrow;
@@ -460,39 +594,51 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // k-steps of a tile: KD for the LINK wave, KO for each of the other two
+    // k-steps of a tile per role.  Measured at N = 10^6, D = 100 (tools/ab_hess.sh): the LINK wave is best left
+    // without MFMA work (KD = 0; 2 / 5 / 5 reads 0.262 ms, 0 / 5 / 7 0.256, 0 / 4 / 8 and 0 / 3 / 9 the same), the
+    // FETCH wave starts its k-steps behind its DMA issue, which keeps the two MFMA waves of a SIMD out of phase.
     constexpr int KSTEPS = TR / 4;
-    constexpr int KD = KSTEPS == 12 ? 2 : 1;
-    constexpr int KO = (KSTEPS - KD) / 2;
-    static_assert(KD + 2 * KO == KSTEPS, "k-step split");
+#ifdef VT_TILE_KD
+    constexpr int KD = VT_TILE_KD;
+#else
+    constexpr int KD = 0;
+#endif
+#ifdef VT_TILE_KF
+    constexpr int KF = VT_TILE_KF;                  // k-steps of the FETCH wave
+#else
+    constexpr int KF = (KSTEPS - KD - 1) / 2;       // 12 k-steps: 5 (+ 7 for the PLAIN wave); 9: 4 + 5
+#endif
+    constexpr int KP = KSTEPS - KD - KF;            // k-steps of the PLAIN wave
+    static_assert(KD >= 0 && KF >= 0 && KP >= 0, "k-step split");
     // prologue: group 0 fetches tile 0
-    if (grp == 0) {
-        dma(0, 0);
-        load_scal(0);
-    }
+    if (grp == 0) dma(0, 0);
     int b0 = 2;                        // buffer of tile p (p = -1: unused)
     int role = grp;                    // 0: LINK, 1: FETCH, 2: PLAIN in this period
     for (int64_t p = -1; p < mine; ++p) {
         const int b1 = b0 == 2 ? 0 : b0 + 1;           // buffer of tile p+1
         const int b2 = b1 == 2 ? 0 : b1 + 1;           // buffer of tile p+2
-        int kfirst = KD + KO, cnt = KO;                 // PLAIN
+        int kfirst = KD + KF, cnt = KP;                 // PLAIN
         if (role == 1) {                                 // FETCH
             kfirst = KD;
-            if (!(VT_ABL & 8)) {
-                dma(p + 2, b2);
-                load_scal(p + 2);
-            }
+            cnt = KF;
+            if (!(VT_ABL & 8)) dma(p + 2, b2);
         } else if (role == 0) {                          // LINK
             kfirst = 0;
             cnt = KD;
             if (!(VT_ABL & 4)) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my own DMA of tile p+1 (issued a period ago)
                 link(p + 1, b1);
+
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (p >= 0) mfma_part(b0, kfirst, cnt);
+#ifdef VT_MFMA_REPEAT   // dev experiment: the period's MFMA work twice (wrong results; separates per-period from per-k-step cost)
+        if (p >= 0) mfma_part(b0, kfirst, cnt);
+#endif
+#ifndef VT_NO_PERIOD_BARRIER   // dev experiment (wrong results)
         vt_lds_barrier();
+#endif
         b0 = b1;
         role = role == 0 ? 2 : role - 1;               // FETCH -> LINK -> PLAIN -> FETCH
     }
@@ -516,11 +662,13 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
             for (int i = 0; i < NB; ++i)
 #pragma unroll
                 for (int j = 0; j <= i; ++j)
-                    if (blk_owner(NB, NQ, i, j) == Q) {
+                    if ((OWN >> blk_ord(NB, i, j)) & 1) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             double* e = hl + (vt_tri(i, j) * 4 + r) * 64 + lane;
-                            const double v = acc[blk_ord(NB, i, j) - FIRST][r];
+                            // strip blocks: rows past the last strip are padding (never stored in H): zeros
+                            const bool live = !(NS > 0 && i == NB - 1) || r < NS;
+                            const double v = live ? acc[slot(blk_ord(NB, i, j))][r] : 0.0;
                             *e = turn == 0 ? v : *e + v;
                         }
                     }
@@ -529,7 +677,7 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
     }
 }
 
-template <int NB, int FAM, bool HAS_OFF>
+template <int NB, int NS, int FAM>
 __global__ __launch_bounds__(kTileThreads) void k_glm_hess_tile(HessArgs a) {
     using LY = TileLds<NB>;
     constexpr int NBT = NB * (NB + 1) / 2;
@@ -541,10 +689,10 @@ __global__ __launch_bounds__(kTileThreads) void k_glm_hess_tile(HessArgs a) {
     const int64_t ntiles = (a.N + LY::TR - 1) / LY::TR;
     const int64_t mine = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3) {   // quarter = SIMD
-        case 0: hess_tile_body<NB, FAM, HAS_OFF, 0>(a, lds, mine); break;
-        case 1: hess_tile_body<NB, FAM, HAS_OFF, 1>(a, lds, mine); break;
-        case 2: hess_tile_body<NB, FAM, HAS_OFF, 2>(a, lds, mine); break;
-        default: hess_tile_body<NB, FAM, HAS_OFF, 3>(a, lds, mine); break;
+        case 0: hess_tile_body<NB, NS, FAM, 0>(a, lds, mine); break;
+        case 1: hess_tile_body<NB, NS, FAM, 1>(a, lds, mine); break;
+        case 2: hess_tile_body<NB, NS, FAM, 2>(a, lds, mine); break;
+        default: hess_tile_body<NB, NS, FAM, 3>(a, lds, mine); break;
     }
     double* out = a.part + (int64_t)blockIdx.x * L;
     for (int e = threadIdx.x; e < NBT * 256; e += kTileThreads) out[e] = lds[e];
@@ -557,7 +705,7 @@ __global__ __launch_bounds__(kTileThreads) void k_glm_hess_tile(HessArgs a) {
 }
 
 inline size_t tile_lds_bytes(int NB) {
-    const size_t loop = (size_t)3 * tile_rows(NB) * tile_rs(NB) + 3 * tile_rows(NB) + NB * 16 + 4 * 32;
+    const size_t loop = (size_t)3 * tile_rows(NB) * tile_rs(NB) + 12 * tile_rows(NB) + NB * 16 + 4 * 32;
     const size_t tail = (size_t)NB * (NB + 1) / 2 * 256 + kTileWaves * NB * 16;
     return std::max(loop, tail) * sizeof(double);
 }
@@ -643,32 +791,39 @@ void launch_hess_small2(const HessArgs& a, int grid, hipStream_t st) {
         hipLaunchKernelGGL((k_glm_hess_small<NB, FAM, false>), dim3(grid), dim3(512), 0, st, a);
 }
 
-template <int NB, int FAM, bool HAS_OFF>
+// hipFuncSetAttribute is per device: one flag per (kernel instantiation, device)
+constexpr int kMaxDev = 64;
+
+template <int NB, int NS, int FAM>
 int launch_hess_tile3(const HessArgs& a, int grid, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_glm_hess_tile<NB, FAM, HAS_OFF>,
+    static bool attr_set[kMaxDev] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return VT_ERR_HIP;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)k_glm_hess_tile<NB, NS, FAM>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return VT_ERR_HIP;
-        attr_set = true;
+        attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((k_glm_hess_tile<NB, FAM, HAS_OFF>), dim3(grid), dim3(kTileThreads), tile_lds_bytes(NB), st, a);
+    hipLaunchKernelGGL((k_glm_hess_tile<NB, NS, FAM>), dim3(grid), dim3(kTileThreads), tile_lds_bytes(NB), st, a);
     return VT_OK;
+}
+
+template <int NB, int NS>
+int launch_hess_tile2(const HessArgs& a, int grid, hipStream_t st) {
+    switch (a.family) {
+        case VT_FAMILY_LOGISTIC: return launch_hess_tile3<NB, NS, VT_FAMILY_LOGISTIC>(a, grid, st);
+        case VT_FAMILY_POISSON: return launch_hess_tile3<NB, NS, VT_FAMILY_POISSON>(a, grid, st);
+        default: return launch_hess_tile3<NB, NS, VT_FAMILY_GAUSSIAN>(a, grid, st);
+    }
 }
 
 template <int NB>
 int launch_hess_tile(const HessArgs& a, int grid, hipStream_t st) {
-    const bool off = a.offset != nullptr;
-    switch (a.family) {
-        case VT_FAMILY_LOGISTIC:
-            return off ? launch_hess_tile3<NB, VT_FAMILY_LOGISTIC, true>(a, grid, st)
-                       : launch_hess_tile3<NB, VT_FAMILY_LOGISTIC, false>(a, grid, st);
-        case VT_FAMILY_POISSON:
-            return off ? launch_hess_tile3<NB, VT_FAMILY_POISSON, true>(a, grid, st)
-                       : launch_hess_tile3<NB, VT_FAMILY_POISSON, false>(a, grid, st);
-        default:
-            return off ? launch_hess_tile3<NB, VT_FAMILY_GAUSSIAN, true>(a, grid, st)
-                       : launch_hess_tile3<NB, VT_FAMILY_GAUSSIAN, false>(a, grid, st);
+    switch (tile_strips(a.D)) {
+        case 1: return launch_hess_tile2<NB, 1>(a, grid, st);
+        case 2: return launch_hess_tile2<NB, 2>(a, grid, st);
+        default: return launch_hess_tile2<NB, 0>(a, grid, st);
     }
 }
 
@@ -725,8 +880,9 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
     }
     const int NB = (D + 15) / 16;
     const int L = slab_len(NB);
-    const bool tiled = N >= kTileMinRows && NB >= 4 && NB <= 8 && (ldx % 2 == 0) && ((uintptr_t)X % 16 == 0) &&
-                       !getenv("VT_HESS_NO_TILE");
+    // dev switch, read once per process: VT_HESS_NO_TILE=1 sends every shape to the register-streaming kernel
+    static const bool no_tile = getenv("VT_HESS_NO_TILE") != nullptr;
+    const bool tiled = N >= kTileMinRows && NB >= 4 && NB <= 8 && (ldx % 2 == 0) && ((uintptr_t)X % 16 == 0) && !no_tile;
     const int64_t ntiles = (N + tile_rows(NB) - 1) / tile_rows(NB);
     const int grid = tiled ? (int)std::min<int64_t>(ntiles, num_cu()) : hess_grid(N);
     double* part = (double*)ws;
@@ -739,16 +895,19 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
                            prior, theta, H, ldh, g);
         return vt_launch_status();
     }
-    static const int ablate = getenv("VT_HESS_ABLATE") ? atoi(getenv("VT_HESS_ABLATE")) : 0;
-    HessArgs a{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, wave_part, sink, ablate};
+    HessArgs a{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, wave_part, sink};
     if (tiled) {
         int rc = VT_ERR_UNSUPPORTED;
         switch (NB) {
+#ifdef VT_HESS_DEV_NB   // dev builds (tools/build_abl.cmd): one block count only, to keep the compile short
+            case VT_HESS_DEV_NB: rc = launch_hess_tile<VT_HESS_DEV_NB>(a, grid, st); break;
+#else
             case 4: rc = launch_hess_tile<4>(a, grid, st); break;
             case 5: rc = launch_hess_tile<5>(a, grid, st); break;
             case 6: rc = launch_hess_tile<6>(a, grid, st); break;
             case 7: rc = launch_hess_tile<7>(a, grid, st); break;
             case 8: rc = launch_hess_tile<8>(a, grid, st); break;
+#endif
         }
         if (rc != VT_OK) return rc;
     } else switch (NB) {
