@@ -243,27 +243,35 @@ __global__ __launch_bounds__(512) void k_glm_hess_small(HessArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Tile kernel (the one that runs for N >= kTileMinRows): 12 waves per CU share TR-row tiles
-// of X through LDS.
+// Tile kernel (the one that runs for N >= kTileMinRows): 12 waves per CU share TR-row tiles of X through LDS.
 //
-// What shapes it (measured on MI355X, tools/micro/mfma_valu_overlap.hip): v_mfma_f64_16x16x4
-// occupies the SIMD's VALU issue for its whole 64 cycles -- three waves of independent MFMAs
-// reach 99 % of the 78.6 TFLOP/s peak, but every VALU instruction of ANY wave on that SIMD
-// adds its own cycles on top (nothing rides "beside" an fp64 MFMA).  So the kernel minimises
-// the VALU instructions executed per MFMA, and keeps every memory operation off the VALU:
-//   * X goes HBM -> LDS by buffer_load_dwordx4 ... lds (one instruction per row, no
-//     registers, no ds_write; padding columns are zero-filled by the descriptor's range
-//     check), two periods ahead of its use, three tile buffers in rotation.
-//   * wave (Q, ks) owns a QUARTER of the block triangle (7 accumulators at D = 100) and
-//     multiplies k-steps ks, ks+3, ... of the tile; A and B operands are ds_read_b64's of
-//     the tile (row stride = 16 mod 32 doubles: conflict free), B scaled by d_n on the way.
-//   * the three waves of a quarter (one SIMD) rotate through three roles, period by period:
-//       FETCH  issues the DMA of its SIMD's rows of tile p+2, then 5 of the 12 k-steps;
-//       LINK   (last period's FETCH wave: it waits for its own DMA only) computes the link of
-//              those rows of tile p+1 -- row dot by DPP; exp, rcp, ... ONCE per row, one lane
-//              per row; gradient; per-row outputs; d_n -> LDS -- then 2 k-steps;
-//       PLAIN  5 k-steps.
-//   period p:  FETCH: DMA(p+2) -> buf[(p+2)%3] | LINK: link(p+1) | all: MFMA(p) from buf[p%3] | barrier
+// What shapes it (measured on MI355X, tools/micro/mfma_valu_overlap.hip, mfma_f64_rate.hip, mfma_f64_4x4.hip):
+// v_mfma_f64_16x16x4 occupies the SIMD's DP pipe for 64 cycles; two or three waves of independent MFMAs reach
+// 99 % of the 78.6 TFLOP/s peak (one wave alone issues one every ~140 cycles), but every VALU instruction of ANY
+// wave on that SIMD adds its own ~4.4 cycles on top (nothing rides "beside" an fp64 MFMA).  So the kernel
+// minimises the VALU instructions executed per MFMA, keeps every memory operation off the VALU, and keeps the
+// waves that issue MFMAs free of everything else:
+//   * X goes HBM -> LDS by buffer_load_dwordx4 ... lds (one instruction per row, no registers, no ds_write;
+//     padding columns are zero-filled by the descriptor's range check), two periods ahead of its use, three
+//     tile buffers in rotation; the per-row scalars y, w, offset ride along the same way (dword DMA), so NO
+//     load of the loop has a VGPR destination and the compiler never parks a wave on s_waitcnt vmcnt(0).
+//   * each SIMD owns a QUARTER of the block triangle (cost-balanced, column-wise: make_own); the rows of the
+//     last block row that exist only as padding are skipped by computing that row with 4x4x4 MFMA strips.
+//   * wave group 0 (one wave per SIMD) is a SERVICE wave: every period it links the SIMD's rows of tile p+1 --
+//     row dot by DPP; exp, rcp, ... ONCE per row, one lane per row; gradient; per-row outputs; d_n -> LDS.
+//     It issues no MFMA, holds no accumulator, and runs its own code region (its registers do not add to the
+//     MFMA waves').
+//   * wave groups 1 and 2 split the k-steps of tile p: A and B operands are ds_read_b64's of the tile (row
+//     stride = 16 mod 32 doubles: conflict free), B scaled by d_n on the way.  Group 1 also issues the DMA of
+//     tile p+2 at the start of the period (SALU + 15 DMA instructions) and waits for it BEFORE the period's
+//     barrier, a whole period later -- which is what lets the service wave link tile p+2 in period p+1 without
+//     a vmcnt wait of its own.
+//   period p:  group 1: DMA(p+2) -> buf[(p+2)%3] | group 0: link(p+1) | groups 1, 2: MFMA(p) from buf[p%3] | barrier
+// History (tools/ab_hess.sh, N = 10^6, D = 100, whole call): three rotating roles with 16x16x4 products only
+// 0.307 ms; + strips 0.272; + column-wise ownership 0.261; + LINK wave without MFMAs 0.256; fixed service wave
+// in its own code region 0.251; + DMA moved to an MFMA wave 0.244.  Did not pay: operand prefetch one k-step
+// ahead, s_setprio for either kind of wave, 16 waves per CU (three MFMA waves per SIMD: same time), one
+// descriptor per tile with the row in the scalar offset (the range check sees it).
 // ---------------------------------------------------------------------------------------
 typedef unsigned vt_u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* vt_ldsptr;
@@ -271,10 +279,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const double* base, 
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
 
-constexpr int kTileThreads = 768;
-constexpr int kTileWaves = 12;
-constexpr int kTileNQ = 4;                     // owners of the block triangle
-constexpr int kTileNK = kTileWaves / kTileNQ;  // 3 waves share a quarter and split the k-steps
+constexpr int kTileNQ = 4;                     // owners of the block triangle (one per SIMD)
+constexpr int kTileNM = 2;                     // MFMA waves per SIMD (3 measured the same)
+constexpr int kTileWaves = kTileNQ * (kTileNM + 1);
+constexpr int kTileThreads = 64 * kTileWaves;
 constexpr int kTileMinRows = 4096;
 
 __host__ __device__ constexpr int tile_rs(int NB) { return (NB & 1) ? 16 * NB : 16 * NB + 16; }
@@ -404,64 +412,147 @@ struct TileLds {   // offsets in doubles
     static constexpr int kTotal = kOff + 3 * TR;
 };
 
-template <int NB, int NS, int FAM, int Q>
-__device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, int64_t mine) {
-    using LY = TileLds<NB>;
-    constexpr int NQ = kTileNQ, NK = kTileNK, RS = LY::RS, TR = LY::TR;
-    constexpr int NBT = NB * (NB + 1) / 2;
-    constexpr OwnTab TAB = make_own(NB, NS, NQ);
-    constexpr bool STRIP = strip_needed(TAB, NB, NS, Q);
-    // ownership as compile-time bit masks (bit blk_ord(i, j) / bit b / bit j): the unrolled loops below test
-    // plain constants -- left to fold blk_owner()'s own loops per iteration, the optimiser sometimes does not
-    constexpr unsigned long long OWN = own_mask(TAB, NB, Q);
-    constexpr int NOWN = __builtin_popcountll(OWN);
-    // accumulator slot of an owned block = its rank among the quarter's blocks
-    auto slot = [](int ord) constexpr { return __builtin_popcountll(OWN & ((1ull << ord) - 1ull)); };
-    constexpr unsigned NEED = need_mask(TAB, NB, NS, Q), COLS = cols_mask(TAB, NB, Q);
-    constexpr int RPS = TR / 4;                        // rows a duty wave links (one wave per SIMD)
-    constexpr int PASSES = (RPS + 3) / 4;
-    constexpr int CH = RS / 2;                         // 16-byte chunks per LDS row
-    constexpr int DMAH = (CH + 63) / 64;               // DMA instructions per row
-    static_assert(TR % kTileWaves == 0 && TR % 4 == 0 && (TR / 4) % NK == 0, "tile shape");
-    static_assert(2 * RPS <= 64, "one DMA instruction moves a SIMD's per-row scalars");
+// Which rows of X a workgroup's k-th tile holds (tiles are dealt round-robin over the grid).
+template <int TR>
+struct TileRows {
+    const HessArgs& a;
+    int64_t mine;
+    __device__ __forceinline__ int64_t first_row(int64_t k) const { return (blockIdx.x + k * (int64_t)gridDim.x) * (int64_t)TR; }
+    __device__ __forceinline__ int nrow(int64_t k) const {
+        const int64_t left = (k >= 0 && k < mine) ? a.N - first_row(k) : 0;
+        return (int)(left < TR ? (left > 0 ? left : 0) : TR);
+    }
+};
 
+// SERVICE wave (wave group 0, one per SIMD): links the RPS rows [RPS*simd, RPS*(simd+1)) of tile p+1 in period p.
+// The tile landed a period ago: MFMA wave 0 of this SIMD issued its DMA and waited for it before the barrier.
+template <int NB, int FAM>
+__device__ __forceinline__ void hess_tile_service(const HessArgs& a, double* lds, int64_t mine, int simd) {
+    using LY = TileLds<NB>;
+    constexpr int RS = LY::RS, TR = LY::TR;
+    constexpr int NBT = NB * (NB + 1) / 2;
+    constexpr int RPS = TR / 4;                        // rows a service wave links
+    constexpr int PASSES = (RPS + 3) / 4;
     const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, c = lane & 15;
-    const int simd = wid & 3, grp = wid >> 2;           // simd == Q; the roles rotate over grp
     const double* th = lds + LY::kTheta;
     double* zs = lds + LY::kScratch + simd * 32;
     // scalar stage of the link: lane t < RPS owns row RPS*simd + t
     const int trow = RPS * simd + (lane & 15);
     const bool tlane = lane < RPS;
-    const int trow_c = trow < TR ? trow : TR - 1;        // in-bounds LDS index for the other lanes
-
-    // accumulators: one f64x4 per owned block; a strip block only ever touches components 0..NS-1
-    f64x4 acc[NOWN > 0 ? NOWN : 1];
-#pragma unroll
-    for (int i = 0; i < NOWN; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const int trow_c = trow < TR ? trow : TR - 1;       // in-bounds LDS index for the other lanes
+    const TileRows<TR> tiles{a, mine};
     double gacc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) gacc[b] = 0.0;
 
-    auto tile_first_row = [&](int64_t k) { return (blockIdx.x + k * (int64_t)gridDim.x) * (int64_t)TR; };
-    auto tile_nrow = [&](int64_t k) -> int {
-        const int64_t left = (k >= 0 && k < mine) ? a.N - tile_first_row(k) : 0;
-        return (int)(left < TR ? (left > 0 ? left : 0) : TR);
+    auto link = [&](int64_t k, int buf) {
+        const int nrow = tiles.nrow(k);
+        const int64_t rb = nrow > 0 ? tiles.first_row(k) : 0;
+        double x[PASSES][NB];
+        // stage 1: z_n = x_n . theta (16 lanes per row)
+#pragma unroll
+        for (int k2 = 0; k2 < PASSES; ++k2) {
+            const int rl = min(4 * k2 + q, RPS - 1);
+            const double* tr = lds + LY::kTile + buf * (TR * RS) + (RPS * simd + rl) * RS + c;
+            double pz = 0.0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                x[k2][b] = tr[16 * b];
+                pz = fma(x[k2][b], th[16 * b + c], pz);
+            }
+            const double z = vt_sum16_dpp(pz);
+            if (c == 0) zs[4 * k2 + q] = z;
+        }
+        // stage 2: the scalar chain, one lane per row
+        {
+            const double sy = lds[LY::kY + buf * TR + trow_c];
+            const double sw = lds[LY::kW + buf * TR + trow_c];
+            const double z = zs[lane & 15] + lds[LY::kOff + buf * TR + trow_c];
+            double l1, l2;
+            vt_link(FAM, z, sy, l1, l2);
+            const bool rowok = tlane && trow < nrow;
+            const double rr = a.scale * l1;
+            const double dw = rowok ? a.scale * sw * l2 : 0.0;
+            const double gwt = rowok ? sw * rr : 0.0;
+            const unsigned so = tlane ? 8u * trow : 0xfffffff0u;    // other lanes: dropped by the range check
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(vt_u32x2, rr),
+                                                  tile_rsrc(a.r_out + rb, a.r_out ? 8u * nrow : 0u), so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(vt_u32x2, dw),
+                                                  tile_rsrc(a.d_out + rb, a.d_out ? 8u * nrow : 0u), so, 0, 0);
+            if (tlane) lds[LY::kD + buf * TR + trow] = dw;
+            if (lane < 16) zs[16 + lane] = gwt;
+        }
+        // stage 3: gradient
+#pragma unroll
+        for (int k2 = 0; k2 < PASSES; ++k2) {
+            const double gwt = (4 * k2 + q < RPS) ? zs[16 + 4 * k2 + q] : 0.0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) gacc[b] = fma(gwt, x[k2][b], gacc[b]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     };
-    // the RPS rows of my SIMD of tile k -> buffer `buf`.  One descriptor per row (SALU only):
-    // lanes past the row's D doubles and rows past N read 0, and the only VGPR is 16 * chunk.
-    // The per-row scalars y, w (offset) of those rows ride along the same way, one dword per lane: NOTHING
-    // the FETCH wave loads has a VGPR destination, so no register hazard makes the compiler park it on
-    // s_waitcnt vmcnt(0) -- i.e. on the HBM latency of its own DMA -- before its MFMA k-steps (it did when
-    // y and w were buffer loads into registers: the allocator reused their registers inside the MFMA loop).
+
+    vt_lds_barrier();                  // tile 0 has landed (MFMA wave 0 fetched it and waited)
+    int b1 = 0;                        // buffer of tile p+1
+    for (int64_t p = -1; p < mine; ++p) {
+        if (!(VT_ABL & 4)) link(p + 1, b1);
+        vt_lds_barrier();
+        b1 = b1 == 2 ? 0 : b1 + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every tile is dead
+    // gradient: the 4 row groups of the wave, one slot per service wave
+    double* gl = lds + NBT * 256;      // [4][NB*16]
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        double v = gacc[b];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (q == 0) gl[simd * (NB * 16) + 16 * b + c] = v;
+    }
+#pragma unroll
+    for (int turn = 0; turn < kTileNM; ++turn) vt_lds_barrier();   // the MFMA waves' reduction turns
+}
+
+// MFMA wave ks (wave group ks + 1) of quarter Q (= SIMD): k-steps [kbeg, kbeg + kcnt) of every tile, for the
+// blocks the quarter owns.  Wave 0 also feeds the pipeline: DMA of tile p+2 at the start of period p.
+template <int NB, int NS, int Q>
+__device__ __forceinline__ void hess_tile_mfma(const HessArgs& a, double* lds, int64_t mine, int ks) {
+    using LY = TileLds<NB>;
+    constexpr int NQ = kTileNQ, RS = LY::RS, TR = LY::TR;
+    constexpr OwnTab TAB = make_own(NB, NS, NQ);
+    constexpr bool STRIP = strip_needed(TAB, NB, NS, Q);
+    // ownership as compile-time bit masks (bit blk_ord(i, j) / bit b / bit j): the unrolled loops below test
+    // plain constants -- left to fold make_own()'s loops per iteration, the optimiser sometimes does not
+    constexpr unsigned long long OWN = own_mask(TAB, NB, Q);
+    constexpr unsigned NEED = need_mask(TAB, NB, NS, Q), COLS = cols_mask(TAB, NB, Q);
+    constexpr int NOWN = __builtin_popcountll(OWN);
+    // accumulator slot of an owned block = its rank among the quarter's blocks
+    auto slot = [](int ord) constexpr { return __builtin_popcountll(OWN & ((1ull << ord) - 1ull)); };
+    constexpr int KSTEPS = TR / 4;
+    constexpr int K0 = KSTEPS / kTileNM;               // wave 0 (which also issues the DMA): 6 of 12, 4 of 9
+    static_assert((KSTEPS - K0) % (kTileNM - 1) == 0, "k-step split");
+    constexpr int KR = (KSTEPS - K0) / (kTileNM - 1);
+    constexpr int RPS = TR / 4;
+    constexpr int CH = RS / 2;                         // 16-byte chunks per LDS row
+    constexpr int DMAH = (CH + 63) / 64;               // DMA instructions per row
+    static_assert(2 * RPS <= 64, "one DMA instruction moves a SIMD's per-row scalars");
+    const int kbeg = ks == 0 ? 0 : K0 + (ks - 1) * KR;
+    const int kcnt = ks == 0 ? K0 : KR;
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, c = lane & 15;
+    const TileRows<TR> tiles{a, mine};
+
+    // the RPS rows of my SIMD of tile k -> buffer `buf`.  One descriptor per row (SALU only): lanes past the
+    // row's D doubles and rows past N read 0, and the only VGPR is 16 * chunk.  The per-row scalars y, w and
+    // offset of those rows ride along the same way, one dword per lane.
     auto dma = [&](int64_t k, int buf) {
-        const int nrow = (VT_ABL & 2) ? 0 : tile_nrow(k);
-        const int64_t rb = nrow > 0 ? tile_first_row(k) : 0;
-        const double* xb = a.X + (rb + RPS * simd) * a.ldx;
+        const int nrow = (VT_ABL & 2) ? 0 : tiles.nrow(k);
+        const int64_t rb = nrow > 0 ? tiles.first_row(k) : 0;
+        const double* xb = a.X + (rb + RPS * Q) * a.ldx;
 #pragma unroll
         for (int rr = 0; rr < RPS; ++rr) {
-            const int row = RPS * simd + rr;
+            const int row = RPS * Q + rr;
             __amdgpu_buffer_rsrc_t xrs = tile_rsrc(xb + (int64_t)rr * a.ldx, row < nrow ? 8u * a.D : 0u);
             double* dst = lds + LY::kTile + buf * (TR * RS) + row * RS;
 #pragma unroll
@@ -472,30 +563,37 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
             }
         }
         if (lane < 2 * RPS) {
-            const unsigned vo = 8u * (RPS * simd) + 4u * lane;
-            const int so = buf * TR + RPS * simd;
+            const unsigned vo = 8u * (RPS * Q) + 4u * lane;
+            const int so = buf * TR + RPS * Q;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(tile_rsrc(a.y + rb, 8u * nrow), (vt_ldsptr)(lds + LY::kY + so), 4, vo, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(tile_rsrc(a.w + rb, 8u * nrow), (vt_ldsptr)(lds + LY::kW + so), 4, vo, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(tile_rsrc(a.offset + rb, a.offset ? 8u * nrow : 0u),
                                                      (vt_ldsptr)(lds + LY::kOff + so), 4, vo, 0, 0, 0);
         }
     };
-    // k-steps [kfirst, kfirst + cnt) of the tile in `buf`.  ONE code path for all three roles, a real
-    // loop with a wave-uniform trip count: when every role had its own unrolled copy, hipcc gave the
-    // accumulators different registers on each path and moved all of them back (28 v_mov_b64 behind an
-    // s_nop 15) every period.
+
+    // accumulators: one f64x4 per owned block; a strip block only ever touches components 0..NS-1
+    f64x4 acc[NOWN > 0 ? NOWN : 1];
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
     const unsigned strip_lane = 8u * (unsigned)(c & 3) - 8u * (unsigned)c;   // byte offset: column c -> column c & 3
-    auto mfma_part = [&](int buf, int kfirst, int cnt) {
-        if (!(VT_ABL & 1)) {
-            // The operand reads are inline asm: as compiler-visible LDS loads they make hipcc wait for the
-            // FETCH wave's own LDS-DMA (vmcnt(0): it cannot tell the tile buffers apart) once the loop
-            // hides the buffer offsets.  (Tried on top of this: two operand sets in rotation, the reads of
-            // k-step m+1 in flight under the MFMAs of m -- no gain, the other two waves of the SIMD
-            // already cover the LDS latency.)
-            unsigned ta = (unsigned)(uintptr_t)(vt_ldsptr)(lds + LY::kTile + buf * (TR * RS) + (q + 4 * kfirst) * RS + c);
-            unsigned da = (unsigned)(uintptr_t)(vt_ldsptr)(lds + LY::kD + buf * TR + q + 4 * kfirst);
+
+    if (ks == 0) {                     // prologue: tile 0, landed before anybody links it
+        dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    vt_lds_barrier();
+    int b0 = 2;                        // buffer of tile p (p = -1: unused)
+    for (int64_t p = -1; p < mine; ++p) {
+        if (ks == 0 && !(VT_ABL & 8)) dma(p + 2, b0 == 0 ? 2 : b0 - 1);   // buffer (p+2) % 3 == buffer of tile p-1
+        if (p >= 0 && !(VT_ABL & 1)) {
+            // The operand reads are inline asm: as compiler-visible LDS loads they make hipcc wait for this
+            // wave's own LDS-DMA (vmcnt(0): it cannot tell the tile buffers apart).  A real loop, not unrolled:
+            // its body is the whole instruction budget of the kernel.
+            unsigned ta = (unsigned)(uintptr_t)(vt_ldsptr)(lds + LY::kTile + b0 * (TR * RS) + (q + 4 * kbeg) * RS + c);
+            unsigned da = (unsigned)(uintptr_t)(vt_ldsptr)(lds + LY::kD + b0 * TR + q + 4 * kbeg);
 #pragma nounroll
-            for (int m = 0; m < cnt; ++m) {
+            for (int m = 0; m < kcnt; ++m) {
                 double xa[8];
                 double xs[2] = {0.0, 0.0};
                 double dq;
@@ -545,119 +643,18 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-    };
-    // Link of the RPS rows [RPS*simd, RPS*(simd+1)) of tile k (in buffer `buf`).
-    auto link = [&](int64_t k, int buf) {
-        const int nrow = tile_nrow(k);
-        const int64_t rb = nrow > 0 ? tile_first_row(k) : 0;
-        double x[PASSES][NB];
-        // stage 1: z_n = x_n . theta (16 lanes per row)
-#pragma unroll
-        for (int k2 = 0; k2 < PASSES; ++k2) {
-            const int rl = min(4 * k2 + q, RPS - 1);
-            const double* tr = lds + LY::kTile + buf * (TR * RS) + (RPS * simd + rl) * RS + c;
-            double pz = 0.0;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                x[k2][b] = tr[16 * b];
-                pz = fma(x[k2][b], th[16 * b + c], pz);
-            }
-            const double z = vt_sum16_dpp(pz);
-            if (c == 0) zs[4 * k2 + q] = z;
-        }
-        // stage 2: the scalar chain, one lane per row
-        {
-            const double sy = lds[LY::kY + buf * TR + trow_c];
-            const double sw = lds[LY::kW + buf * TR + trow_c];
-            double z = zs[lane & 15] + lds[LY::kOff + buf * TR + trow_c];
-            double l1, l2;
-            vt_link(FAM, z, sy, l1, l2);
-            const bool rowok = tlane && trow < nrow;
-            const double rr = a.scale * l1;
-            const double dw = rowok ? a.scale * sw * l2 : 0.0;
-            const double gwt = rowok ? sw * rr : 0.0;
-            const unsigned so = tlane ? 8u * trow : 0xfffffff0u;    // other lanes: dropped by the range check
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(vt_u32x2, rr),
-                                                  tile_rsrc(a.r_out + rb, a.r_out ? 8u * nrow : 0u), so, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(vt_u32x2, dw),
-                                                  tile_rsrc(a.d_out + rb, a.d_out ? 8u * nrow : 0u), so, 0, 0);
-            if (tlane) lds[LY::kD + buf * TR + trow] = dw;
-            if (lane < 16) zs[16 + lane] = gwt;
-        }
-        // stage 3: gradient
-#pragma unroll
-        for (int k2 = 0; k2 < PASSES; ++k2) {
-            const double gwt = (4 * k2 + q < RPS) ? zs[16 + 4 * k2 + q] : 0.0;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) gacc[b] = fma(gwt, x[k2][b], gacc[b]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // k-steps of a tile per role.  Measured at N = 10^6, D = 100 (tools/ab_hess.sh): the LINK wave is best left
-    // without MFMA work (KD = 0; 2 / 5 / 5 reads 0.262 ms, 0 / 5 / 7 0.256, 0 / 4 / 8 and 0 / 3 / 9 the same), the
-    // FETCH wave starts its k-steps behind its DMA issue, which keeps the two MFMA waves of a SIMD out of phase.
-    constexpr int KSTEPS = TR / 4;
-#ifdef VT_TILE_KD
-    constexpr int KD = VT_TILE_KD;
-#else
-    constexpr int KD = 0;
-#endif
-#ifdef VT_TILE_KF
-    constexpr int KF = VT_TILE_KF;                  // k-steps of the FETCH wave
-#else
-    constexpr int KF = (KSTEPS - KD - 1) / 2;       // 12 k-steps: 5 (+ 7 for the PLAIN wave); 9: 4 + 5
-#endif
-    constexpr int KP = KSTEPS - KD - KF;            // k-steps of the PLAIN wave
-    static_assert(KD >= 0 && KF >= 0 && KP >= 0, "k-step split");
-    // prologue: group 0 fetches tile 0
-    if (grp == 0) dma(0, 0);
-    int b0 = 2;                        // buffer of tile p (p = -1: unused)
-    int role = grp;                    // 0: LINK, 1: FETCH, 2: PLAIN in this period
-    for (int64_t p = -1; p < mine; ++p) {
-        const int b1 = b0 == 2 ? 0 : b0 + 1;           // buffer of tile p+1
-        const int b2 = b1 == 2 ? 0 : b1 + 1;           // buffer of tile p+2
-        int kfirst = KD + KF, cnt = KP;                 // PLAIN
-        if (role == 1) {                                 // FETCH
-            kfirst = KD;
-            cnt = KF;
-            if (!(VT_ABL & 8)) dma(p + 2, b2);
-        } else if (role == 0) {                          // LINK
-            kfirst = 0;
-            cnt = KD;
-            if (!(VT_ABL & 4)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my own DMA of tile p+1 (issued a period ago)
-                link(p + 1, b1);
-
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (p >= 0) mfma_part(b0, kfirst, cnt);
-#ifdef VT_MFMA_REPEAT   // dev experiment: the period's MFMA work twice (wrong results; separates per-period from per-k-step cost)
-        if (p >= 0) mfma_part(b0, kfirst, cnt);
-#endif
-#ifndef VT_NO_PERIOD_BARRIER   // dev experiment (wrong results)
+        // my DMA of tile p+2, issued a whole period ago in wall time: landed before the barrier, so the service
+        // wave may link it in the next period
+        if (ks == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         vt_lds_barrier();
-#endif
-        b0 = b1;
-        role = role == 0 ? 2 : role - 1;               // FETCH -> LINK -> PLAIN -> FETCH
+        b0 = b0 == 2 ? 0 : b0 + 1;
     }
-    __syncthreads();   // every tile is dead
-
-    // ---- gradient: the 4 row groups of the wave, one slot per wave -----------------------------
-    double* hl = lds;               // [NBT*256]
-    double* gl = lds + NBT * 256;   // [kTileWaves][NB*16]
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every tile is dead
+    // H: the MFMA waves of a quarter add up in LDS in the order ks = 0, 1, ...
+    double* hl = lds;                  // [NBT*256]
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        double v = gacc[b];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (q == 0) gl[wid * (NB * 16) + 16 * b + c] = v;
-    }
-    // ---- H: the NK waves of a quarter add up in LDS in the order ks = 0, 1, 2 --------------------
-#pragma unroll
-    for (int turn = 0; turn < NK; ++turn) {
-        if (grp == turn) {
+    for (int turn = 0; turn < kTileNM; ++turn) {
+        if (ks == turn) {
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -673,7 +670,7 @@ __device__ __forceinline__ void hess_tile_body(const HessArgs& a, double* lds, i
                         }
                     }
         }
-        __syncthreads();
+        vt_lds_barrier();
     }
 }
 
@@ -688,25 +685,31 @@ __global__ __launch_bounds__(kTileThreads) void k_glm_hess_tile(HessArgs a) {
     __syncthreads();
     const int64_t ntiles = (a.N + LY::TR - 1) / LY::TR;
     const int64_t mine = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3) {   // quarter = SIMD
-        case 0: hess_tile_body<NB, NS, FAM, 0>(a, lds, mine); break;
-        case 1: hess_tile_body<NB, NS, FAM, 1>(a, lds, mine); break;
-        case 2: hess_tile_body<NB, NS, FAM, 2>(a, lds, mine); break;
-        default: hess_tile_body<NB, NS, FAM, 3>(a, lds, mine); break;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int simd = wid & 3, grp = wid >> 2;
+    if (grp == 0) {
+        hess_tile_service<NB, FAM>(a, lds, mine, simd);
+    } else {
+        switch (simd) {   // quarter = SIMD
+            case 0: hess_tile_mfma<NB, NS, 0>(a, lds, mine, grp - 1); break;
+            case 1: hess_tile_mfma<NB, NS, 1>(a, lds, mine, grp - 1); break;
+            case 2: hess_tile_mfma<NB, NS, 2>(a, lds, mine, grp - 1); break;
+            default: hess_tile_mfma<NB, NS, 3>(a, lds, mine, grp - 1); break;
+        }
     }
     double* out = a.part + (int64_t)blockIdx.x * L;
     for (int e = threadIdx.x; e < NBT * 256; e += kTileThreads) out[e] = lds[e];
     for (int t = threadIdx.x; t < NB * 16; t += kTileThreads) {
-        double s = 0.0;
+        double s2 = 0.0;
 #pragma unroll
-        for (int w = 0; w < kTileWaves; ++w) s += lds[NBT * 256 + w * (NB * 16) + t];
-        out[NBT * 256 + t] = s;
+        for (int w = 0; w < 4; ++w) s2 += lds[NBT * 256 + w * (NB * 16) + t];
+        out[NBT * 256 + t] = s2;
     }
 }
 
 inline size_t tile_lds_bytes(int NB) {
     const size_t loop = (size_t)3 * tile_rows(NB) * tile_rs(NB) + 12 * tile_rows(NB) + NB * 16 + 4 * 32;
-    const size_t tail = (size_t)NB * (NB + 1) / 2 * 256 + kTileWaves * NB * 16;
+    const size_t tail = (size_t)NB * (NB + 1) / 2 * 256 + 4 * NB * 16;
     return std::max(loop, tail) * sizeof(double);
 }
 
