@@ -371,13 +371,29 @@ struct TrsmSched {
     }
 };
 
+// Row strips of the LAST block row.  When the trailing partial block has KL <= 2 k-steps (D mod 16 in 1..8) only
+// the first 4 KL parameter rows of block row NB-1 exist, and its products are computed by KL
+// v_mfma_f64_4x4x4_4b per k-step (16 pipe cycles each) instead of one 64-cycle 16x16x4 product: the four 4x4
+// blocks of that instruction take the SAME 4 rows of the A image (lane l reads the image at lane
+// (l & 48) | (4 r + (l & 3))) against the four 4-column groups of the ordinary B operand, and result lane L holds
+// row 4 r + (L >> 4), right-hand side L & 15: exactly register r of the 16x16 accumulator (see vt_hessian.hip).
+// D = 100: 26 of the 200 products of a tile shrink from 64 to 16 cycles (-9.75 % of the MFMA pipe time).
+template <int NB, int KL, bool LASTPERM>
+struct TrsmSched2 : TrsmSched<NB, KL, LASTPERM> {
+    static constexpr int STRIPS = (!LASTPERM && KL <= 2) ? KL : 0;
+    static constexpr bool strip_row(int idx) { return STRIPS > 0 && TrsmSched<NB, KL, LASTPERM>::row(idx) == NB - 1; }
+    static constexpr int NSET = STRIPS > 1 ? STRIPS : 1;     // A-operand sets per k-step
+};
+
 template <int NB, int KL, bool LASTPERM>
 struct TrsmState {
+    static constexpr int NSET = TrsmSched2<NB, KL, LASTPERM>::NSET;
     f64x4 V[NB];
     f64x4 acc;
-    double cur[4], nxt[4];
+    double cur[4][NSET], nxt[4][NSET];
     const double* lds;
     int lane, q;
+    int slane[NSET];   // lane of the A image a strip product reads
     double* orow;  // output row of this lane
     bool store_fwd, store_bwd;   // store Y after the forward chain (forward-only solves) / Z after the backward chain
     int D;
@@ -398,31 +414,53 @@ __device__ __forceinline__ void trsm_store(TrsmState<NB, KL, LASTPERM>& st) {
     }
 }
 
+// A operand(s) of product IDX -> dst
+template <int IDX, int NB, int KL, bool LASTPERM>
+__device__ __forceinline__ void trsm_fetch(TrsmState<NB, KL, LASTPERM>& st, double (&dst)[4][TrsmState<NB, KL, LASTPERM>::NSET]) {
+    using S = TrsmSched2<NB, KL, LASTPERM>;
+    constexpr int img = S::image(IDX);
+    constexpr int nks = S::ks(S::src(IDX));
+    if constexpr (S::strip_row(IDX)) {
+#pragma unroll
+        for (int s = 0; s < nks; ++s)
+#pragma unroll
+            for (int r = 0; r < S::STRIPS; ++r) dst[s][r] = st.lds[(img * 4 + s) * 64 + st.slane[r]];
+    } else {
+#pragma unroll
+        for (int s = 0; s < nks; ++s) dst[s][0] = st.lds[(img * 4 + s) * 64 + st.lane];
+    }
+}
+
 // Products [IDX, END) of the schedule; st.cur holds the A operand of product IDX on entry.
 template <int IDX, int END, int NB, int KL, bool LASTPERM>
 __device__ __forceinline__ void trsm_chain(TrsmState<NB, KL, LASTPERM>& st) {
-    using S = TrsmSched<NB, KL, LASTPERM>;
+    using S = TrsmSched2<NB, KL, LASTPERM>;
     if constexpr (IDX < END) {
-        if constexpr (IDX + 1 < END) {
-            constexpr int img = S::image(IDX + 1);
-            constexpr int nks = S::ks(S::src(IDX + 1));
-#pragma unroll
-            for (int s = 0; s < nks; ++s) st.nxt[s] = st.lds[(img * 4 + s) * 64 + st.lane];
-        }
+        if constexpr (IDX + 1 < END) trsm_fetch<IDX + 1, NB, KL, LASTPERM>(st, st.nxt);
         __builtin_amdgcn_sched_barrier(0);
         constexpr int i = S::src(IDX), j = S::row(IDX);
         constexpr int cks = S::ks(i);
         constexpr bool is_first = S::first(IDX), is_last = S::last(IDX), is_bwd = S::bwd(IDX);
         if constexpr (is_first) st.acc = (f64x4){0.0, 0.0, 0.0, 0.0};
+        if constexpr (S::strip_row(IDX)) {
 #pragma unroll
-        for (int s = 0; s < cks; ++s) st.acc = mfma_f64(st.cur[s], st.V[i][s], st.acc);
+            for (int s = 0; s < cks; ++s)
+#pragma unroll
+                for (int r = 0; r < S::STRIPS; ++r)
+                    st.acc[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(st.cur[s][r], st.V[i][s], st.acc[r], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < cks; ++s) st.acc = mfma_f64(st.cur[s][0], st.V[i][s], st.acc);
+        }
         if constexpr (is_last) {
             st.V[j] = st.acc;
             if (is_bwd ? st.store_bwd : st.store_fwd) trsm_store<j, NB, KL, LASTPERM>(st);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) st.cur[s] = st.nxt[s];
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int r = 0; r < S::NSET; ++r) st.cur[s][r] = st.nxt[s][r];
         trsm_chain<IDX + 1, END, NB, KL, LASTPERM>(st);
     }
 }
@@ -445,6 +483,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
     st.lane = lane;
     st.q = q;
     st.D = a.D;
+#pragma unroll
+    for (int r = 0; r < TrsmState<NB, KL, LASTPERM>::NSET; ++r) st.slane[r] = (lane & 48) | (4 * r + (lane & 3));
 
     f64x4 Gn[NB];  // next tile's right-hand side (prefetch)
     double coefn;
@@ -503,17 +543,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
         st.orow = a.Out + (rowok ? row : 0) * a.ldo;
         if constexpr (PREFETCH) load_group(grp + W < ngroups ? grp + W : grp);
         if (a.mode != 2) {   // forward substitution  L Y = G
-            constexpr int img = S::image(0);
-            constexpr int nks = S::ks(S::src(0));
-#pragma unroll
-            for (int s = 0; s < nks; ++s) st.cur[s] = lds[(img * 4 + s) * 64 + lane];
+            trsm_fetch<0, NB, KL, LASTPERM>(st, st.cur);
             trsm_chain<0, NBT, NB, KL, LASTPERM>(st);
         }
         if (a.mode != 1) {   // backward substitution  L^T Z = Y
-            constexpr int img = S::image(NBT);
-            constexpr int nks = S::ks(S::src(NBT));
-#pragma unroll
-            for (int s = 0; s < nks; ++s) st.cur[s] = lds[(img * 4 + s) * 64 + lane];
+            trsm_fetch<NBT, NB, KL, LASTPERM>(st, st.cur);
             trsm_chain<NBT, 2 * NBT, NB, KL, LASTPERM>(st);
         }
     }
