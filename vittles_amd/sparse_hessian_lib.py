@@ -151,23 +151,181 @@ class SparseBlockHessian():
         return total
 
 
+def matrix_fingerprint(mat):
+    """Cheap check that a scipy sparse matrix still holds the values a device-side structure snapshot was
+    taken from (an in-place edit of ``.data`` keeps Python attributes alive): shape, nnz and two sums."""
+    data = np.asarray(mat.data, dtype=np.float64)
+    return (tuple(mat.shape), int(mat.nnz), float(data.sum()), float(np.abs(data).sum()))
+
+
 def _attach(mat, struct):
     mat._vt_structure = struct
+    mat._vt_fingerprint = matrix_fingerprint(mat)
     if struct.covers_everything():
         mat._vt_solver = struct.make_solver
+
+
+MAX_BLOCK = 64      # vt_arrow_* kernels: block size M and number of globals Kg
+
+
+def detect_arrowhead(h, sparsity_array=None, global_inds=None):
+    """Recover the block-arrowhead structure H = [[blockdiag(B_g), C], [C^T, Gm]] of a symmetric scipy
+    sparse matrix from its sparsity pattern (or take it from explicit ``sparsity_array`` (G, M) / ``global_inds``).
+
+    Global indices: rows whose degree exceeds what a local row can have (M + Kg <= 2 * MAX_BLOCK); if a
+    connected component of what remains is still larger than MAX_BLOCK, its highest-degree node joins the
+    globals, and so on (at most MAX_BLOCK globals).  Blocks: the connected components of the rest.  They need not
+    be index ranges nor of one size: components are packed (first fit, largest first) into G bins of
+    M = largest component, and a bin that is not full is topped up with PADDING indices d, d+1, ... (decoupled
+    unknowns with a unit diagonal that the solver adds and drops again).
+
+    Returns (inds (G, M) int64, global_inds (Kg,) int64, d_pad) or None when the matrix is not of that form."""
+    import scipy.sparse.csgraph
+    d = h.shape[0]
+    if sparsity_array is not None:
+        inds = np.asarray(sparsity_array, dtype=np.int64)
+        if inds.ndim != 2 or len(np.unique(inds)) != inds.size:
+            raise ValueError('The indices in ``sparsity array`` must be unique.')
+        if global_inds is None:
+            global_inds = np.setdiff1d(np.arange(d), inds.reshape(-1))
+        ginds = np.asarray(global_inds, dtype=np.int64)
+        if len(np.intersect1d(ginds, inds.reshape(-1))) > 0:
+            raise ValueError('The global and local indices must be disjoint.')
+        if inds.size + ginds.size != d:
+            return None
+        return inds, ginds, d
+    coo = scipy.sparse.coo_matrix(h)
+    off = coo.row != coo.col
+    r, c = coo.row[off], coo.col[off]
+    degree = np.bincount(r, minlength=d) + 1
+    local = np.ones(d, dtype=bool)
+    if global_inds is None:
+        local[degree > 2 * MAX_BLOCK] = False
+    else:
+        local[np.asarray(global_inds, dtype=np.int64)] = False
+    for _ in range(MAX_BLOCK + 1):
+        if d - int(local.sum()) > MAX_BLOCK:
+            return None
+        keep = local[r] & local[c]
+        graph = scipy.sparse.coo_matrix((np.ones(int(keep.sum()), dtype=np.int8), (r[keep], c[keep])), (d, d))
+        ncomp, labels = scipy.sparse.csgraph.connected_components(graph, directed=False)
+        sizes = np.bincount(labels[local], minlength=ncomp)      # global nodes are singletons of size 0 here
+        big = np.nonzero(sizes > MAX_BLOCK)[0]
+        if big.size == 0:
+            break
+        if global_inds is not None:
+            return None                                           # the caller named the globals: no guessing
+        # the best-connected node of every oversized component becomes a global
+        deg_local = np.bincount(r[keep], minlength=d)
+        for comp in big:
+            members = np.nonzero((labels == comp) & local)[0]
+            local[members[np.argmax(deg_local[members])]] = False
+    else:
+        return None
+    ginds = np.nonzero(~local)[0].astype(np.int64)
+    lidx = np.nonzero(local)[0]
+    if lidx.size == 0:
+        return None
+    # components (members in ascending index order), largest first
+    lab = labels[lidx]
+    order = np.argsort(lab, kind="stable")
+    members_sorted = lidx[order]
+    comp_ids, starts, counts = np.unique(lab[order], return_index=True, return_counts=True)
+    M = int(counts.max())
+    if np.all(counts == M):
+        return members_sorted.reshape(-1, M).astype(np.int64), ginds, d
+    # first-fit-decreasing into bins of capacity M; by size class this is a counting problem, so it is done per
+    # size class instead of per component: fill every open bin with the largest remaining components that fit
+    by_size = np.argsort(-counts, kind="stable")
+    bins = []           # lists of member arrays
+    room = []           # free slots per bin
+    open_by_room = {}   # free slots -> stack of bin numbers
+    for ci in by_size:
+        sz = int(counts[ci])
+        mem = members_sorted[starts[ci]:starts[ci] + sz]
+        slot = None
+        for free in range(sz, M):                 # tightest open bin that still fits (best fit)
+            stack = open_by_room.get(free)
+            if stack:
+                slot = stack.pop()
+                break
+        if slot is None:
+            bins.append([mem])
+            room.append(M - sz)
+            slot = len(bins) - 1
+        else:
+            bins[slot].append(mem)
+            room[slot] -= sz
+        if room[slot] > 0:
+            open_by_room.setdefault(room[slot], []).append(slot)
+    G = len(bins)
+    inds = np.empty((G, M), dtype=np.int64)
+    pad = d
+    for g, parts in enumerate(bins):
+        row = np.concatenate(parts)
+        if row.size < M:
+            npad = M - row.size
+            row = np.concatenate([row, np.arange(pad, pad + npad)])
+            pad += npad
+        inds[g] = row
+    return inds, ginds, pad
+
+
+def arrowhead_from_sparse(h, device=None, sparsity_array=None, global_inds=None):
+    """``ArrowheadStructure`` (device images of the blocks, border and corner) of a scipy sparse matrix whose
+    pattern is block-arrowhead, or None.  O(nnz) host work, no densification."""
+    found = detect_arrowhead(h, sparsity_array, global_inds)
+    if found is None:
+        return None
+    inds, ginds, d_pad = found
+    G, M = inds.shape
+    Kg = int(ginds.size)
+    if M > MAX_BLOCK or Kg > MAX_BLOCK:
+        return None
+    d = h.shape[0]
+    coo = scipy.sparse.coo_matrix(h)
+    comp = np.full(d_pad, -1, dtype=np.int64)   # block of a local index
+    pos = np.zeros(d_pad, dtype=np.int64)       # position inside its block / among the globals
+    comp[inds.reshape(-1)] = np.repeat(np.arange(G), M)
+    pos[inds.reshape(-1)] = np.tile(np.arange(M), G)
+    pos[ginds] = np.arange(Kg)
+    r, c, v = coo.row, coo.col, np.asarray(coo.data, dtype=np.float64)
+    rl, cl = comp[r] >= 0, comp[c] >= 0
+    ll = rl & cl
+    if np.any(comp[r[ll]] != comp[c[ll]]):
+        return None                              # an entry couples two different blocks
+    blocks = np.zeros((G, M, M))
+    np.add.at(blocks, (comp[r[ll]], pos[r[ll]], pos[c[ll]]), v[ll])      # duplicates are summed (COO rule)
+    if d_pad > d:                                # padding unknowns: unit diagonal, coupled to nothing
+        padi = np.arange(d, d_pad)
+        blocks[comp[padi], pos[padi], pos[padi]] = 1.0
+    border = corner = None
+    if Kg > 0:
+        border = np.zeros((G * M, Kg))
+        lg = rl & ~cl
+        np.add.at(border, (comp[r[lg]] * M + pos[r[lg]], pos[c[lg]]), v[lg])
+        corner = np.zeros((Kg, Kg))
+        gg = ~rl & ~cl
+        np.add.at(corner, (pos[r[gg]], pos[c[gg]]), v[gg])
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    to = lambda x: None if x is None else torch.as_tensor(x).to(device)
+    return ArrowheadStructure(to(inds), to(blocks), to(border), to(corner), to(ginds) if Kg > 0 else None, d,
+                              d_pad=d_pad)
 
 
 class ArrowheadStructure:
     """Device images of H = [[blockdiag(B_g), C], [C^T, Gm]] and its batched solver (K8)."""
 
-    def __init__(self, inds, blocks, border, corner, ginds, d):
+    def __init__(self, inds, blocks, border, corner, ginds, d, d_pad=None):
         self.inds, self.blocks, self.border, self.corner, self.ginds, self.d = inds, blocks, border, corner, ginds, d
+        self.d_pad = d if d_pad is None else int(d_pad)    # d + padding unknowns (detect_arrowhead)
         self.G, self.M = blocks.shape[0], blocks.shape[1]
         self.Kg = 0 if ginds is None else int(ginds.shape[0])
         self._factored = None
 
     def covers_everything(self):
-        return self.G * self.M + self.Kg == self.d
+        return self.G * self.M + self.Kg == self.d_pad
 
     def _factor(self):
         if self._factored is not None:
@@ -196,16 +354,20 @@ class ArrowheadStructure:
             raise _lib.VittlesHipError("block structure does not cover the whole matrix")
         L, W, schur_chol = self._factor()
         lib = dev.require_gpu()
-        G, M, Kg, d = self.G, self.M, self.Kg, self.d
+        G, M, Kg, d, d_pad = self.G, self.M, self.Kg, self.d, self.d_pad
         devc = L.device
 
         def solve(v):
             vd = dev.to_device(v, devc)
             one_d = vd.ndim == 1
-            V = (vd.reshape(d, 1) if one_d else vd).contiguous()
-            if V.shape[0] != d:
+            if vd.shape[0] != d:
                 raise ValueError("right-hand side must have %d rows" % d)
+            V = (vd.reshape(d, 1) if one_d else vd).contiguous()
             nrhs = V.shape[1]
+            if d_pad > d:                     # padding unknowns: zero right-hand side, dropped from the result
+                Vp = torch.zeros((d_pad, nrhs), dtype=torch.float64, device=devc)
+                Vp[:d] = V
+                V = Vp
             x = torch.empty_like(V)
             tpart = torch.empty((G, max(Kg, 1), nrhs), dtype=torch.float64, device=devc)
             rhs_g = torch.empty((max(Kg, 1), nrhs), dtype=torch.float64, device=devc)
@@ -219,6 +381,7 @@ class ArrowheadStructure:
                 _lib.check(lib.vt_arrow_back(W.data_ptr(), self.inds.data_ptr(), self.ginds.data_ptr(),
                                              xg.data_ptr(), x.data_ptr(), G, M, Kg, nrhs, dev.stream_ptr()),
                            "vt_arrow_back")
+            x = x[:d]
             out = x.reshape(d) if one_d else x
             return dev.like_input(out, v)
         return solve
