@@ -83,11 +83,19 @@ class LinearResponseCovariances:
             raise ValueError(err_msg)
 
         # moment_jacobian1 @ hess_solver(moment_jacobian2.T), products on the device:
-        # Z = H^{-1} J2^T is (d, K2); row i of the result is Z^T J1[i, :]  (K9 kernel).
+        # Z = H^{-1} J2^T is (d, K2); the result (J1^T)^T Z is ONE fp64-MFMA product over the d axis
+        # (vt_gemm_tn; outside its shape limits: one streaming pass per moment).
         J1 = dev.to_device(moment_jacobian1)
-        J2 = dev.to_device(moment_jacobian2)
-        Z = dev.to_device(self.hess_solver(J2.t().contiguous())).contiguous()
-        out = torch.stack([rows.gemv_t(Z, J1[i].contiguous()) for i in range(J1.shape[0])])
+        same = moment_jacobian2 is moment_jacobian1
+        J2t = (J1 if same else dev.to_device(moment_jacobian2)).t().contiguous()       # (d, K2)
+        Z = dev.to_device(self.hess_solver(J2t)).contiguous()
+        K1, K2 = J1.shape[0], Z.shape[1]
+        if 1 <= K1 <= 8192 and 1 <= K2 <= 8192:
+            J1t = J2t if same else J1.t().contiguous()                                   # (d, K1)
+            out = rows.gemm_tn(J1t, Z)
+        else:
+            out = torch.stack([rows.gemv_t(Z, J1[i].contiguous()) for i in range(K1)]) if K1 > 0 \
+                else torch.empty((0, K2), dtype=torch.float64, device=Z.device)
         return dev.like_input(out, moment_jacobian1)
 
     def get_moment_jacobian(self, calculate_moments):

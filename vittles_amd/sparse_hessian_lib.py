@@ -37,6 +37,7 @@ class SparseBlockHessian():
                 'objective_function must be a registered objective exposing hvp(opt_par, v) '
                 '(autograd is not part of this build).')
         self._inds_dev = None
+        self._host_cache = None
 
     # -- helpers -------------------------------------------------------------------------
     def _device(self):
@@ -56,14 +57,18 @@ class SparseBlockHessian():
                                            v.data_ptr(), v.shape[0], dev.stream_ptr()), "vt_block_colour_vec")
         return self._fun.hvp(opt_par, v)
 
-    def _block_parts(self, opt_par, print_every=0):
+    def _block_parts(self, opt_par, print_every=0, out=None):
+        """COO triplets (reference order) + dense block images of the block part, on the device.  ``out``:
+        optional (vals, rows, cols) views of a larger buffer to fill (get_hessian packs both parts in one)."""
         lib = dev.require_gpu()
         G, M = self._num_blocks, self._block_size
         devc = opt_par.device
         nnz = G * M * M
-        vals = torch.empty(nnz, dtype=torch.float64, device=devc)
-        rows = torch.empty(nnz, dtype=torch.int64, device=devc)
-        cols = torch.empty(nnz, dtype=torch.int64, device=devc)
+        if out is None:
+            out = (torch.empty(nnz, dtype=torch.float64, device=devc),
+                   torch.empty(nnz, dtype=torch.int64, device=devc),
+                   torch.empty(nnz, dtype=torch.int64, device=devc))
+        vals, rows, cols = out
         blocks = torch.empty((G, M, M), dtype=torch.float64, device=devc)
         for ib in range(M):
             if print_every > 0:
@@ -85,11 +90,11 @@ class SparseBlockHessian():
         opt = dev.to_device(opt_par, self._device()).contiguous()
         vals, rows, cols, blocks = self._block_parts(opt, print_every)
         d = opt.shape[0]
-        h_sparse = coo_matrix((vals.cpu().numpy(), (rows.cpu().numpy(), cols.cpu().numpy())), (d, d))
+        h_sparse = coo_matrix(_triplets_to_host(vals, rows, cols, d), (d, d))
         _attach(h_sparse, ArrowheadStructure(self._inds(), blocks, None, None, None, d))
         return h_sparse
 
-    def _global_parts(self, opt, global_inds, print_every=0):
+    def _global_parts(self, opt, global_inds, print_every=0, out=None):
         lib = dev.require_gpu()
         devc = opt.device
         G, M = self._num_blocks, self._block_size
@@ -97,9 +102,11 @@ class SparseBlockHessian():
         local = self._inds().reshape(-1)
         ginds = torch.as_tensor(np.ascontiguousarray(global_inds, dtype=np.int64)).to(devc)
         per = 2 * nloc + 2 * Kg
-        vals = torch.empty(Kg * per, dtype=torch.float64, device=devc)
-        rows = torch.empty(Kg * per, dtype=torch.int64, device=devc)
-        cols = torch.empty(Kg * per, dtype=torch.int64, device=devc)
+        if out is None:
+            out = (torch.empty(Kg * per, dtype=torch.float64, device=devc),
+                   torch.empty(Kg * per, dtype=torch.int64, device=devc),
+                   torch.empty(Kg * per, dtype=torch.int64, device=devc))
+        vals, rows, cols = out
         border = torch.empty((nloc, max(Kg, 1)), dtype=torch.float64, device=devc)
         corner = torch.empty((max(Kg, 1), max(Kg, 1)), dtype=torch.float64, device=devc)
         v = torch.zeros(opt.shape[0], dtype=torch.float64, device=devc)
@@ -134,21 +141,66 @@ class SparseBlockHessian():
         if len(global_inds) == 0:
             return coo_matrix((d, d))
         vals, rows, cols, border, corner, ginds = self._global_parts(opt, global_inds, print_every)
-        h_sparse = coo_matrix((vals.cpu().numpy(), (rows.cpu().numpy(), cols.cpu().numpy())), (d, d))
+        h_sparse = coo_matrix(_triplets_to_host(vals, rows, cols, d), (d, d))
         h_sparse._vt_global = (border, corner, ginds)
         return h_sparse
 
     def get_hessian(self, opt_par, print_every=0):
-        # reference :165-168
-        local_hessian = self.get_block_hessian(opt_par, print_every=print_every)
-        global_hessian = self.get_global_hessian(opt_par, print_every=print_every)
-        total = local_hessian + global_hessian
-        struct = local_hessian._vt_structure
-        glob = getattr(global_hessian, '_vt_global', None)
-        if glob is not None:
-            struct = ArrowheadStructure(struct.inds, struct.blocks, glob[0], glob[1], glob[2], struct.d)
+        """Block + global Hessian (reference :165-168 returns ``local_hessian + global_hessian``, which SciPy
+        sums into a CSR matrix on the host).  Here the triplets of BOTH parts are gathered into one device
+        buffer in the reference's order (block part first) and cross the bus once; the result is a single
+        ``coo_matrix`` holding exactly the entries the reference adds up (duplicates -- the two 0.5*h halves of
+        a global pair -- are summed by SciPy on conversion, as in ``+``)."""
+        opt_np = np.atleast_1d(opt_par) if not isinstance(opt_par, torch.Tensor) else opt_par
+        if opt_np.ndim != 1:
+            raise ValueError('``opt_par`` must be a vector.')
+        opt = dev.to_device(opt_par, self._device()).contiguous()
+        d = opt.shape[0]
+        devc = opt.device
+        # the default global indices (reference :114-116) and the (row, col) arrays of the result depend on the
+        # sparsity array and d only: computed once, kept on the host
+        cache = self._host_cache if getattr(self, '_host_cache', None) and self._host_cache['d'] == d else None
+        if cache is None:
+            global_inds = np.setdiff1d(np.arange(d), np.hstack(self._sparsity_array))
+            cache = self._host_cache = dict(d=d, global_inds=global_inds, ij=None)
+        global_inds = cache['global_inds']
+        G, M = self._num_blocks, self._block_size
+        Kg = len(global_inds)
+        nb = G * M * M
+        ng = Kg * (2 * G * M + 2 * Kg)
+        vals = torch.empty(nb + ng, dtype=torch.float64, device=devc)
+        rows = torch.empty(nb + ng, dtype=torch.int64, device=devc)
+        cols = torch.empty(nb + ng, dtype=torch.int64, device=devc)
+        _, _, _, blocks = self._block_parts(opt, print_every, out=(vals[:nb], rows[:nb], cols[:nb]))
+        struct = ArrowheadStructure(self._inds(), blocks, None, None, None, d)
+        if Kg > 0:
+            _, _, _, border, corner, ginds = self._global_parts(opt, global_inds, print_every,
+                                                                out=(vals[nb:], rows[nb:], cols[nb:]))
+            struct = ArrowheadStructure(self._inds(), blocks, border, corner, ginds, d)
+        if cache['ij'] is None:
+            hv, ij = _triplets_to_host(vals, rows, cols, d)
+            cache['ij'] = (ij[0].copy(), ij[1].copy())
+        else:                                   # only the values cross the bus; every result owns its index arrays
+            hv, ij = vals.cpu().numpy(), (cache['ij'][0].copy(), cache['ij'][1].copy())
+        total = coo_matrix((hv, ij), (d, d))
         _attach(total, struct)
         return total
+
+
+def _triplets_to_host(vals, rows, cols, d):
+    """(vals f64, rows, cols) device tensors -> numpy arrays in ONE device-to-host copy; indices travel as int32
+    when they fit (SciPy's own index type for such matrices)."""
+    n = vals.shape[0]
+    if d < 2 ** 31:
+        packed = torch.empty(2 * n, dtype=torch.float64, device=vals.device)
+        packed[:n] = vals
+        idx = packed[n:].view(torch.int32)          # 2 n int32 slots: rows then cols
+        idx[:n] = rows
+        idx[n:] = cols
+        host = packed.cpu().numpy()
+        ij = host[n:].view(np.int32)
+        return host[:n], (ij[:n], ij[n:])
+    return vals.cpu().numpy(), (rows.cpu().numpy(), cols.cpu().numpy())
 
 
 def matrix_fingerprint(mat):
