@@ -247,19 +247,23 @@ int    vt_cg_update(double* p_dev, const double* q_dev, double* x_dev, double* r
 /* ---- K7: hierarchical mean-field Gaussian VI objective (BASELINE.json configs[4]) --------
  * Model and parameter layout: see oracle/vi.py / vittles_amd/objectives.py.
  * eta = [m_0 v_0 ... m_{G-1} v_{G-1} m_mu v_mu], d = 2k(G+1); X is (G*ng, k) row-major.
+ * global_terms: 1 = the whole objective.  0 = a SHARD of the groups (one rank of a group-sharded objective)
+ * that does not own the terms of the global rows / of the value that are not sums over groups (mu's prior
+ * and entropy): the shards' global rows (the last 2k entries of out) and values then add up to the whole
+ * objective's -- one all-reduce of 2k doubles (collective C3).
  * Replaces: autograd.grad(f) and the forward-over-reverse HVP `_f_fwd_hess`
  *             vittles/sparse_hessian_lib.py:59-60 (vittles/sensitivity_lib.py:440-492),
  *             vittles/lr_cov_lib.py:77-80, for this registered objective. */
 size_t vt_vi_workspace_bytes(int G, int k);
 int    vt_vi_hvp(const double* X_dev, const double* w_dev, const double* eta_dev, const double* u_dev,
-                 double tau_y, double tau_th, double tau_mu, int G, int ng, int k, double* out_dev,
-                 void* ws_dev, size_t ws_bytes, void* stream);
+                 double tau_y, double tau_th, double tau_mu, int G, int ng, int k, int global_terms,
+                 double* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
 int    vt_vi_grad(const double* X_dev, const double* y_dev, const double* w_dev, const double* eta_dev,
-                  double tau_y, double tau_th, double tau_mu, int G, int ng, int k, double* out_dev,
-                  void* ws_dev, size_t ws_bytes, void* stream);
+                  double tau_y, double tau_th, double tau_mu, int G, int ng, int k, int global_terms,
+                  double* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
 int    vt_vi_value(const double* X_dev, const double* y_dev, const double* w_dev, const double* eta_dev,
-                   double tau_y, double tau_th, double tau_mu, int G, int ng, int k, double* value_dev,
-                   void* ws_dev, size_t ws_bytes, void* stream);
+                   double tau_y, double tau_th, double tau_mu, int G, int ng, int k, int global_terms,
+                   double* value_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
 /* ---- K7: SparseBlockHessian assembly ------------------------------------------------------
  * vt_block_colour_vec: v <- 0; v[inds[b, ib]] = 1 for all b

@@ -97,6 +97,69 @@ def glm_checks(rank, world, group, family, N, D):
     return dict(family=family, N=N, D=D, rows=(a, b))
 
 
+def vi_checks(rank, world, group):
+    """Group-sharded hierarchical VI path: objective derivatives, block + global Hessian,
+    the arrowhead solver with all-reduced Schur complement / global right-hand side, and the LR covariance,
+    against the oracle on ALL groups."""
+    import torch
+    import vittles_amd as va
+    from vittles_amd import sharding
+    from oracle import vi, lr_cov
+    G, ng, k = 37, 7, 3
+    taus = (2.0, 1.5, 0.5)
+    X, y = vi.synth(G, ng, k, 3)
+    m = vi.HierGaussMFVI(X, y, G, ng, k, *taus)
+    g0, g1 = sharding.shard_rows(G, rank, world)
+    Gl = g1 - g0
+    obj = va.HierGaussMFVIObjective(X[g0 * ng:g1 * ng], y[g0 * ng:g1 * ng], Gl, ng, k, *taus, process_group=group)
+    nl, ngl = 2 * k * Gl, 2 * k
+
+    def loc(vec):      # this rank's slice of a full-layout vector: its groups' entries + the globals
+        return np.concatenate([vec[2 * k * g0:2 * k * g1], vec[2 * k * G:]])
+    rng = np.random.default_rng(8)
+    eta = m.optimum() * (1.0 + 0.03 * rng.random(m.d))
+    w = 0.5 + rng.random(G * ng)
+    u = rng.standard_normal(m.d)
+    wl = w[g0 * ng:g1 * ng]
+    assert abs(obj(loc(eta), wl) - m.value(eta, w)) <= 1e-11 * abs(m.value(eta, w))
+    assert rel(obj.grad(loc(eta), wl).cpu().numpy(), loc(m.grad(eta, w))) < 1e-11
+    assert rel(obj.hvp(loc(eta), loc(u), wl).cpu().numpy(), loc(m.hvp(eta, u, w))) < 1e-11
+
+    eta0 = m.optimum()
+    sb = va.SparseBlockHessian(obj, obj.sparsity_array())
+    H = sb.get_hessian(loc(eta0))
+    Hd = m.hessian(eta0)
+    sel = np.concatenate([np.arange(2 * k * g0, 2 * k * g1), np.arange(2 * k * G, m.d)])
+    # the rank's matrix is H restricted to its (local + global) unknowns, with the FULL global corner
+    assert rel(np.asarray(H.todense()), Hd[np.ix_(sel, sel)]) < 1e-11
+    # the sharded solve == the matching rows of the global solve (Schur complement summed over ranks)
+    b = rng.standard_normal((m.d, 2))
+    x_ref = np.linalg.solve(Hd, b)
+    solve = va.solver_lib.get_cholesky_solver(H)
+    x = solve(b[sel])
+    assert rel(x, x_ref[sel]) < 1e-10, ("arrow solve", rel(x, x_ref[sel]))
+    # LR covariance of moments that live on different ranks and on the globals
+    K = 6
+    J = np.zeros((K, m.d))
+    J[0, 0] = 1.0                      # m of group 0 (rank 0)
+    J[1, 2 * k * (G - 1) + 1] = 1.0    # m of the last group (rank 1)
+    J[2, 2 * k * G] = 1.0              # m_mu
+    J[3, 2 * k * G + k] = 1.0          # v_mu
+    J[4] = rng.standard_normal(m.d)    # dense moments
+    J[5] = rng.standard_normal(m.d)
+    lr = va.LinearResponseCovariances(obj, loc(eta0), validate_optimum=True, hessian_at_opt=H, grad_tol=1e-6)
+    cov = lr.get_lr_covariance_from_jacobians(J[:, sel], J[:, sel])
+    cov_ref = J @ np.linalg.solve(Hd, J.T)
+    assert rel(cov, cov_ref) < 1e-10, ("lr cov", rel(cov, cov_ref))
+    # off the optimum the Newton-step validation must fail on EVERY rank alike (all-reduced norm)
+    try:
+        va.LinearResponseCovariances(obj, loc(eta), validate_optimum=True, hessian_at_opt=H, grad_tol=1e-12)
+        raise AssertionError("validation should have failed")
+    except ValueError as e:
+        assert "newton_step" in str(e)
+    return dict(vi=True, groups=(g0, g1))
+
+
 def main():
     import torch
     import torch.distributed as dist

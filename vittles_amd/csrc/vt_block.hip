@@ -24,6 +24,8 @@ struct ViArgs {
     int G, ng, k;
     double* out;       // (2k(G+1)) gradient / HVP
     double* gpart;     // (G, k+1): per-group contributions to the global rows / the value
+    int global_terms;  // 1: the whole objective; 0: a shard of the groups that does NOT own the terms of the
+                       //    global rows / the value that are not sums over groups (mu's prior and entropy)
 };
 
 enum { VI_HVP = 0, VI_GRAD = 1, VI_VALUE = 2 };
@@ -109,17 +111,21 @@ __global__ __launch_bounds__(1024) void k_vi_global(ViArgs a, double* value_out)
         __syncthreads();
         if (tid == 0) {
             int64_t base = (int64_t)G * 2 * k;
+            // a shard (global_terms == 0) contributes only what is a sum over its groups; the shards' global
+            // rows / values then ADD UP to the whole objective's
+            const double once = a.global_terms ? 1.0 : 0.0;
+            const double tmu = once * a.tau_mu;
             if (MODE == VI_HVP) {
                 const double* ummu = a.u + base;
                 const double* uvmu = ummu + k;
-                a.out[base + j] = -a.tau_th * tot + (G * a.tau_th + a.tau_mu) * ummu[j];
-                a.out[base + k + j] = 0.5 / (vmu[j] * vmu[j]) * uvmu[j];
+                a.out[base + j] = -a.tau_th * tot + (G * a.tau_th + tmu) * ummu[j];
+                a.out[base + k + j] = once * (0.5 / (vmu[j] * vmu[j]) * uvmu[j]);
             } else if (MODE == VI_GRAD) {
-                a.out[base + j] = -a.tau_th * tot + a.tau_mu * mmu[j];
-                a.out[base + k + j] = 0.5 * (G * a.tau_th + a.tau_mu) - 0.5 / vmu[j];
+                a.out[base + j] = -a.tau_th * tot + tmu * mmu[j];
+                a.out[base + k + j] = 0.5 * (G * a.tau_th + tmu) - once * (0.5 / vmu[j]);
             } else {
-                total_val += tot + 0.5 * a.tau_th * G * vmu[j] + 0.5 * a.tau_mu * (mmu[j] * mmu[j] + vmu[j]) -
-                             0.5 * log(vmu[j]);
+                total_val += tot + 0.5 * a.tau_th * G * vmu[j] + 0.5 * tmu * (mmu[j] * mmu[j] + vmu[j]) -
+                             once * (0.5 * log(vmu[j]));
             }
         }
     }
@@ -298,12 +304,12 @@ __global__ void k_arrow_back(const double* W, const int64_t* inds, const int64_t
 
 }  // namespace
 
-#define VI_ARGS ViArgs a{X, y, w, eta, u, tau_y, tau_th, tau_mu, G, ng, k, out, gpart}
+#define VI_ARGS ViArgs a{X, y, w, eta, u, tau_y, tau_th, tau_mu, G, ng, k, out, gpart, global_terms}
 
 extern "C" size_t vt_vi_workspace_bytes(int G, int k) { return (size_t)G * (k + 1) * sizeof(double); }
 
 extern "C" int vt_vi_hvp(const double* X, const double* w, const double* eta, const double* u, double tau_y,
-                         double tau_th, double tau_mu, int G, int ng, int k, double* out, void* ws,
+                         double tau_th, double tau_mu, int G, int ng, int k, int global_terms, double* out, void* ws,
                          size_t ws_bytes, void* stream) {
     if (!X || !w || !eta || !u || !out || G < 1 || ng < 1 || k < 1) return VT_ERR_BAD_ARG;
     if (!ws || ws_bytes < vt_vi_workspace_bytes(G, k)) return VT_ERR_WORKSPACE;
@@ -314,7 +320,7 @@ extern "C" int vt_vi_hvp(const double* X, const double* w, const double* eta, co
 }
 
 extern "C" int vt_vi_grad(const double* X, const double* y, const double* w, const double* eta, double tau_y,
-                          double tau_th, double tau_mu, int G, int ng, int k, double* out, void* ws,
+                          double tau_th, double tau_mu, int G, int ng, int k, int global_terms, double* out, void* ws,
                           size_t ws_bytes, void* stream) {
     if (!X || !y || !w || !eta || !out || G < 1 || ng < 1 || k < 1) return VT_ERR_BAD_ARG;
     if (!ws || ws_bytes < vt_vi_workspace_bytes(G, k)) return VT_ERR_WORKSPACE;
@@ -325,7 +331,8 @@ extern "C" int vt_vi_grad(const double* X, const double* y, const double* w, con
 }
 
 extern "C" int vt_vi_value(const double* X, const double* y, const double* w, const double* eta, double tau_y,
-                           double tau_th, double tau_mu, int G, int ng, int k, double* value_out, void* ws,
+                           double tau_th, double tau_mu, int G, int ng, int k, int global_terms, double* value_out,
+                           void* ws,
                            size_t ws_bytes, void* stream) {
     if (!X || !y || !w || !eta || !value_out || G < 1 || ng < 1 || k < 1) return VT_ERR_BAD_ARG;
     if (!ws || ws_bytes < vt_vi_workspace_bytes(G, k)) return VT_ERR_WORKSPACE;

@@ -1,7 +1,7 @@
 // Library-level entry points: version, error strings, device probe.
 #include "vt_common.h"
 
-extern "C" int vt_version(void) { return 100; }
+extern "C" int vt_version(void) { return 101; }   // 101: global_terms argument of vt_vi_*
 
 extern "C" const char* vt_error_string(int code) {
     switch (code) {

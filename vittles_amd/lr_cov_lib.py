@@ -21,6 +21,10 @@ class LinearResponseCovariances:
         # reference :43-86
         self._obj_fun = objective_fun
         self._grad_tol = grad_tol
+        # a group-sharded registered objective (one rank per GPU): this rank's opt_par is [its local entries ...,
+        # n_global replicated global entries]; sums over the parameter axis are all-reduced, globals counted once
+        self._group = getattr(objective_fun, 'process_group', None)
+        self._n_global = int(getattr(objective_fun, 'n_global', 0)) if self._group is not None else 0
         self.set_base_values(opt_par_value, hessian_at_opt, factorize_hessian, validate=validate_optimum)
 
     def set_base_values(self, opt_par_value, hessian_at_opt, factorize_hessian=True,
@@ -49,13 +53,24 @@ class LinearResponseCovariances:
                     '(autograd is not part of this build).')
             grad0 = self._obj_fun.grad(dev.to_device(self._opt0))
             newton_step = -1 * self.hess_solver(grad0)
-            newton_step_norm = float(torch.linalg.vector_norm(dev.to_device(newton_step)).item())
+            newton_step_norm = self._param_norm(dev.to_device(newton_step))
             if newton_step_norm > grad_tol:
                 err_msg = \
                     'The gradient is not zero at the proposed optimal ' + \
                     'values.  ||newton_step|| = {} > {} = grad_tol'.format(
                         newton_step_norm, grad_tol)
                 raise ValueError(err_msg)
+
+    def _param_norm(self, vec):
+        """2-norm over the WHOLE parameter vector: for a sharded objective the local entries of every rank plus
+        the replicated globals once."""
+        if self._group is None:
+            return float(torch.linalg.vector_norm(vec).item())
+        from . import sharding
+        nl = vec.shape[0] - self._n_global
+        sq = (vec[:nl] * vec[:nl]).sum().reshape(1)
+        sharding.all_reduce_sum(sq, self._group)
+        return float((sq[0] + (vec[nl:] * vec[nl:]).sum()).sqrt().item())
 
     def get_hessian_at_opt(self):
         return self._hess0
@@ -90,7 +105,16 @@ class LinearResponseCovariances:
         J2t = (J1 if same else dev.to_device(moment_jacobian2)).t().contiguous()       # (d, K2)
         Z = dev.to_device(self.hess_solver(J2t)).contiguous()
         K1, K2 = J1.shape[0], Z.shape[1]
-        if 1 <= K1 <= 8192 and 1 <= K2 <= 8192:
+        if self._group is not None:
+            # sharded: every rank holds the columns of the Jacobians that belong to ITS parameters (+ the
+            # replicated global columns); the sum over the parameter axis is all-reduced, globals counted once
+            from . import sharding
+            J1t = J1.t().contiguous()
+            if sharding.group_rank(self._group) != 0 and self._n_global > 0:
+                J1t[J1t.shape[0] - self._n_global:] = 0.0
+            out = rows.gemm_tn(J1t, Z) if (1 <= K1 <= 8192 and 1 <= K2 <= 8192) else J1t.t() @ Z
+            sharding.all_reduce_sum(out, self._group)
+        elif 1 <= K1 <= 8192 and 1 <= K2 <= 8192:
             J1t = J2t if same else J1.t().contiguous()                                   # (d, K1)
             out = rows.gemm_tn(J1t, Z)
         else:

@@ -169,7 +169,12 @@ class HierGaussMFVIObjective(RegisteredObjective):
     It is a callable ``f(opt_par[, weights])`` like the reference expects, and carries its
     gradient and HVP as HIP kernels (the reference would use autograd)."""
 
-    def __init__(self, X, y, G, ng, k, tau_y=1.0, tau_th=1.0, tau_mu=1.0, device=None):
+    def __init__(self, X, y, G, ng, k, tau_y=1.0, tau_th=1.0, tau_mu=1.0, device=None, process_group=None):
+        """``process_group``: the GROUPS are sharded over the ranks of that torch.distributed group (one process
+        per GPU): this rank holds ``G`` of them (``X``, ``y`` of its groups only) and its
+        ``opt_par`` is [its groups' (m_g, v_g) ..., m_mu, v_mu] with the globals replicated.  Gradients / HVPs
+        return this rank's local rows plus the ALL-REDUCED global rows (2k doubles), the value is all-reduced;
+        mu's prior and entropy are contributed by rank 0 only."""
         dev.require_gpu()
         self.G, self.ng, self.k = int(G), int(ng), int(k)
         self.X = dev.to_device(X, device).reshape(self.G * self.ng, self.k).contiguous()
@@ -179,10 +184,19 @@ class HierGaussMFVIObjective(RegisteredObjective):
             raise ValueError("y must have G*ng entries")
         self.tau = (float(tau_y), float(tau_th), float(tau_mu))
         self.d = 2 * self.k * (self.G + 1)
+        self.n_global = 2 * self.k                  # trailing entries of opt_par shared by all ranks
+        self.process_group = process_group
+        self._global_terms = 1 if sharding.group_rank(process_group) == 0 else 0
         self._ones = torch.ones(self.G * self.ng, dtype=torch.float64, device=self.device)
         lib = _lib.load()
         self._ws = torch.empty(lib.vt_vi_workspace_bytes(self.G, self.k) // 8 + 1, dtype=torch.float64,
                                device=self.device)
+
+    def _reduce_global_rows(self, out):
+        """Sum the partial global rows (last 2k entries) over the ranks of a group-sharded objective."""
+        if self.process_group is not None:
+            sharding.all_reduce_sum(out[self.d - self.n_global:], self.process_group)
+        return out
 
     def sparsity_array(self):
         return np.arange(2 * self.k * self.G).reshape(self.G, 2 * self.k)
@@ -207,8 +221,9 @@ class HierGaussMFVIObjective(RegisteredObjective):
         opt = self._check(opt)
         val = torch.empty(1, dtype=torch.float64, device=self.device)
         _lib.check(lib.vt_vi_value(self.X.data_ptr(), self.y.data_ptr(), self._w(hyper).data_ptr(), opt.data_ptr(),
-                                   *self.tau, self.G, self.ng, self.k, val.data_ptr(), self._ws.data_ptr(),
-                                   self._ws.numel() * 8, dev.stream_ptr()), "vt_vi_value")
+                                   *self.tau, self.G, self.ng, self.k, self._global_terms, val.data_ptr(),
+                                   self._ws.data_ptr(), self._ws.numel() * 8, dev.stream_ptr()), "vt_vi_value")
+        sharding.all_reduce_sum(val, self.process_group)
         return float(val.item())
 
     def grad(self, opt, hyper=None):
@@ -216,9 +231,9 @@ class HierGaussMFVIObjective(RegisteredObjective):
         opt = self._check(opt)
         out = torch.empty(self.d, dtype=torch.float64, device=self.device)
         _lib.check(lib.vt_vi_grad(self.X.data_ptr(), self.y.data_ptr(), self._w(hyper).data_ptr(), opt.data_ptr(),
-                                  *self.tau, self.G, self.ng, self.k, out.data_ptr(), self._ws.data_ptr(),
-                                  self._ws.numel() * 8, dev.stream_ptr()), "vt_vi_grad")
-        return out
+                                  *self.tau, self.G, self.ng, self.k, self._global_terms, out.data_ptr(),
+                                  self._ws.data_ptr(), self._ws.numel() * 8, dev.stream_ptr()), "vt_vi_grad")
+        return self._reduce_global_rows(out)
 
     def hvp(self, opt, vec, hyper=None, out=None):
         lib = dev.require_gpu()
@@ -227,9 +242,9 @@ class HierGaussMFVIObjective(RegisteredObjective):
         if out is None:
             out = torch.empty(self.d, dtype=torch.float64, device=self.device)
         _lib.check(lib.vt_vi_hvp(self.X.data_ptr(), self._w(hyper).data_ptr(), opt.data_ptr(), vec.data_ptr(),
-                                 *self.tau, self.G, self.ng, self.k, out.data_ptr(), self._ws.data_ptr(),
-                                 self._ws.numel() * 8, dev.stream_ptr()), "vt_vi_hvp")
-        return out
+                                 *self.tau, self.G, self.ng, self.k, self._global_terms, out.data_ptr(),
+                                 self._ws.data_ptr(), self._ws.numel() * 8, dev.stream_ptr()), "vt_vi_hvp")
+        return self._reduce_global_rows(out)
 
     def hessian(self, opt, hyper=None):
         """Dense (d, d) Hessian by d HVPs -- small problems only (tests, validation)."""

@@ -81,3 +81,14 @@ def agree_scalars(values, group, device):
     t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if staged else device)
     dist.broadcast(t, src=dist.get_global_rank(group, 0), group=group)
     return [float(v) for v in t.tolist()]
+
+
+def all_reduce_max(values, group, device):
+    """Maximum over the ranks of a list of Python floats (status codes, norms): every rank gets the result."""
+    if group is None:
+        return list(values)
+    import torch.distributed as dist
+    staged = dist.get_backend(group) != "nccl"
+    t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if staged else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return [float(v) for v in t.tolist()]

@@ -17,7 +17,7 @@ import scipy.sparse
 import torch
 from scipy.sparse import coo_matrix
 
-from . import _lib, device as dev
+from . import _lib, device as dev, sharding
 
 
 class SparseBlockHessian():
@@ -172,11 +172,12 @@ class SparseBlockHessian():
         rows = torch.empty(nb + ng, dtype=torch.int64, device=devc)
         cols = torch.empty(nb + ng, dtype=torch.int64, device=devc)
         _, _, _, blocks = self._block_parts(opt, print_every, out=(vals[:nb], rows[:nb], cols[:nb]))
-        struct = ArrowheadStructure(self._inds(), blocks, None, None, None, d)
+        group = getattr(self._fun, 'process_group', None)
+        struct = ArrowheadStructure(self._inds(), blocks, None, None, None, d, process_group=group)
         if Kg > 0:
             _, _, _, border, corner, ginds = self._global_parts(opt, global_inds, print_every,
                                                                 out=(vals[nb:], rows[nb:], cols[nb:]))
-            struct = ArrowheadStructure(self._inds(), blocks, border, corner, ginds, d)
+            struct = ArrowheadStructure(self._inds(), blocks, border, corner, ginds, d, process_group=group)
         if cache['ij'] is None:
             hv, ij = _triplets_to_host(vals, rows, cols, d)
             cache['ij'] = (ij[0].copy(), ij[1].copy())
@@ -369,9 +370,13 @@ def arrowhead_from_sparse(h, device=None, sparsity_array=None, global_inds=None)
 class ArrowheadStructure:
     """Device images of H = [[blockdiag(B_g), C], [C^T, Gm]] and its batched solver (K8)."""
 
-    def __init__(self, inds, blocks, border, corner, ginds, d, d_pad=None):
+    def __init__(self, inds, blocks, border, corner, ginds, d, d_pad=None, process_group=None):
         self.inds, self.blocks, self.border, self.corner, self.ginds, self.d = inds, blocks, border, corner, ginds, d
         self.d_pad = d if d_pad is None else int(d_pad)    # d + padding unknowns (detect_arrowhead)
+        # blocks sharded over the ranks of this group (each rank: its blocks + the replicated globals, the FULL
+        # corner): the Schur complement and the globals' right-hand side are all-reduced (Kg x Kg, Kg x nrhs),
+        # the block factorisations and local solves need no communication (SURVEY.md section 8e)
+        self.process_group = process_group
         self.G, self.M = blocks.shape[0], blocks.shape[1]
         self.Kg = 0 if ginds is None else int(ginds.shape[0])
         self._factored = None
@@ -391,12 +396,20 @@ class ArrowheadStructure:
         W = torch.empty((G * M, max(Kg, 1)), dtype=torch.float64, device=devc)
         spart = torch.empty((G, max(Kg * Kg, 1)), dtype=torch.float64, device=devc)
         schur = torch.empty((max(Kg, 1), max(Kg, 1)), dtype=torch.float64, device=devc)
-        _lib.check(lib.vt_arrow_factor(L.data_ptr(), dev.ptr(self.border), dev.ptr(self.corner), W.data_ptr(),
+        corner = self.corner
+        group = self.process_group
+        if group is not None and Kg > 0 and sharding.group_rank(group) != 0:
+            corner = torch.zeros_like(self.corner)          # the corner enters the Schur complement once
+        _lib.check(lib.vt_arrow_factor(L.data_ptr(), dev.ptr(self.border), dev.ptr(corner), W.data_ptr(),
                                        spart.data_ptr(), schur.data_ptr(), G, M, Kg, info.data_ptr(),
                                        dev.stream_ptr()), "vt_arrow_factor")
         k = int(info.item())
+        if group is not None:
+            (k,) = [int(v) for v in sharding.all_reduce_max([float(k)], group, devc)]
         if k > 0:
             raise np.linalg.LinAlgError("block Hessian is not positive definite (pivot %d)" % k)
+        if group is not None and Kg > 0:
+            sharding.all_reduce_sum(schur, group)           # Gm - sum over ALL ranks' groups of C_g^T B_g^-1 C_g
         schur_chol = DeviceCholesky.factor(schur) if Kg > 0 else None
         self._factored = (L, W, schur_chol)
         return self._factored
@@ -428,6 +441,7 @@ class ArrowheadStructure:
                                                 rhs_g.data_ptr(), G, M, Kg, nrhs, dev.stream_ptr()),
                        "vt_arrow_local_solve")
             if Kg > 0:
+                sharding.all_reduce_sum(rhs_g, self.process_group)     # -sum over all ranks' groups of C_g^T y_g
                 rhs_g += V[self.ginds]
                 xg = schur_chol.solve(rhs_g).contiguous()
                 _lib.check(lib.vt_arrow_back(W.data_ptr(), self.inds.data_ptr(), self.ginds.data_ptr(),
