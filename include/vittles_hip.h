@@ -244,6 +244,13 @@ int    vt_cg_init(const double* b_dev, const double* q0_dev, double* r_dev, doub
 int    vt_cg_update(double* p_dev, const double* q_dev, double* x_dev, double* r_dev, int64_t D,
                     double* scal_dev, void* stream);
 
+/* out_dev[0] = sum_i a_i b_i c_i  (c_dev NULL: sum_i a_i b_i), one workgroup, fixed summation order.
+ * Replaces: the NumPy reductions around the path -- np.linalg.norm of the estimating equation / of the Newton
+ *             step (vittles/sensitivity_lib.py:209, vittles/lr_cov_lib.py:112), and the prior term of the
+ *             objective value -- so that no library reduction kernel sits in the optimiser's loop. */
+int    vt_dot3(const double* a_dev, const double* b_dev, const double* c_dev, int64_t n, double* out_dev,
+               void* stream);
+
 /* ---- K7: hierarchical mean-field Gaussian VI objective (BASELINE.json configs[4]) --------
  * Model and parameter layout: see oracle/vi.py / vittles_amd/objectives.py.
  * eta = [m_0 v_0 ... m_{G-1} v_{G-1} m_mu v_mu], d = 2k(G+1); X is (G*ng, k) row-major.

@@ -44,9 +44,13 @@ def link4(family, z):
     return np.zeros_like(z)
 
 
-def input_derivs(family, X, y, theta, w, dw, prior=None, scale=1.0, offset=None, max_order=2):
-    """[d theta/dw . dw,  d^2 theta/dw^2 [dw, dw]] at (theta, w) (reference: evaluate_input_derivs,
-    sensitivity_lib.py:1273-1285)."""
+def input_derivs(family, X, y, theta, w, dw, prior=None, scale=1.0, offset=None, max_order=2,
+                 max_input_order=None):
+    """[d theta/dw . dw,  d^2 theta/dw^2 [dw, dw], ...] at (theta, w) (reference: evaluate_input_derivs,
+    sensitivity_lib.py:1273-1285).  ``max_input_order``: the reference drops every term whose number of
+    partial derivatives w.r.t. the input (``total_eta_order``) exceeds it (:1247-1249); a term
+    ``w l_{m+1} (...) x`` is an m-th input partial of G, a term ``dw l_{m+1} (...) x`` an m-th input and
+    first hyper partial (l_k = k-th link derivative)."""
     if max_order < 1 or (max_order > 3 and family != "gaussian"):
         raise ValueError("oracle covers orders 1 to 3 (any order for the gaussian family)")
     z = glm.linear_predictor(X, theta, offset)
@@ -55,16 +59,19 @@ def input_derivs(family, X, y, theta, w, dw, prior=None, scale=1.0, offset=None,
     chol = scipy.linalg.cho_factor(glm.hessian(family, X, y, theta, w, prior, scale, offset))
     d1 = -scipy.linalg.cho_solve(chol, X.T @ (scale * l1 * dw))
     out = [d1]
+    mio = np.inf if max_input_order is None else max_input_order
     if max_order >= 2:
         t = X @ d1
-        rhs = X.T @ (scale * (w * l3 * t * t + 2.0 * dw * l2 * t))
+        rhs = X.T @ (scale * ((w * l3 * t * t if mio >= 2 else 0.0) + 2.0 * dw * l2 * t))
         out.append(-scipy.linalg.cho_solve(chol, rhs))
     if max_order >= 3 and family != "gaussian":
         # third total derivative of (w + t dw) * dl(z(t)), z(t) = z + t z1 + t^2/2 z2 + t^3/6 z3, without the
         # w l2 z3 term (that one is H d3):  w (l4 z1^3 + 3 l3 z1 z2) + 3 dw (l3 z1^2 + l2 z2)
         z1, z2 = X @ out[0], X @ out[1]
         l4 = link4(family, z)
-        rhs = X.T @ (scale * (w * (l4 * z1 ** 3 + 3.0 * l3 * z1 * z2) + 3.0 * dw * (l3 * z1 ** 2 + l2 * z2)))
+        rhs = X.T @ (scale * ((w * l4 * z1 ** 3 if mio >= 3 else 0.0) +
+                              (3.0 * w * l3 * z1 * z2 + 3.0 * dw * l3 * z1 ** 2 if mio >= 2 else 0.0) +
+                              3.0 * dw * l2 * z2))
         out.append(-scipy.linalg.cho_solve(chol, rhs))
         return out
     for k in range(3, max_order + 1):

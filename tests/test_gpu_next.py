@@ -170,6 +170,36 @@ def test_taylor_expansion_orders_1_2_match_oracle(family, N, D, relerr):
         te.evaluate_taylor_series(w + dw, max_order=0)
 
 
+@pytest.mark.parametrize("family", ["logistic", "poisson"])
+def test_taylor_expansion_max_input_order_truncates_like_the_reference(family, relerr, capsys):
+    """the reference drops every term with more than ``max_input_order`` partial derivatives w.r.t.
+    the input (vittles/sensitivity_lib.py:1247-1249); orders 2 and 3 then differ from the untruncated series."""
+    import vittles_amd as va
+    from oracle import glm, taylor
+    N, D = 3000, 17
+    X, y, w, _ = glm.synth(N, D, family, seed=77)
+    rng = np.random.default_rng(6)
+    w = 0.5 + rng.random(N)
+    dw = rng.random(N) - 0.5
+    theta = glm.newton_optimum(family, X, y, w, prior=1.0)
+    obj = va.WeightedGLMObjective(X, y, family=family, prior=1.0)
+    full = taylor.input_derivs(family, X, y, theta, w, dw, 1.0, max_order=3)
+    for mio in (1, 2, 3):
+        te = va.ParametricSensitivityTaylorExpansion.optimization_objective(obj, theta, w, order=3,
+                                                                            max_input_order=mio)
+        ref = taylor.input_derivs(family, X, y, theta, w, dw, 1.0, max_order=3, max_input_order=mio)
+        got = te.evaluate_input_derivs(dw)
+        for k in range(3):
+            assert relerr(got[k], ref[k]) < 1e-10, (mio, k)
+        if mio < 3:          # the truncation really changes the result
+            assert relerr(ref[2], full[2]) > 1e-6
+    te.print_terms()
+    out = capsys.readouterr().out
+    assert "Terms for order 3:" in out and "eps[1]" in out
+    with pytest.raises(ValueError):
+        te.print_terms(k=4)
+
+
 def test_taylor_expansion_reference_regression_kat():
     """vittles/tests/test_sensitivity_lib.py:838-901 (orders 1 and 2 of its four), 6 decimals as there:
     f = sum_n w_n (y_n - x_n theta)^2 is the gaussian family with scale 2 and no prior."""

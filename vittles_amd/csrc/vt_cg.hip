@@ -92,3 +92,30 @@ extern "C" int vt_cg_update(double* p, const double* q, double* x, double* r, in
     hipLaunchKernelGGL(k_cg_update, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, q, x, r, D, scal);
     return vt_launch_status();
 }
+
+// out[0] = sum_i a_i b_i (c_i): the small vector reductions of the host layer -- dot products, squared norms
+// (a == b), the prior term sum_j prior_j theta_j^2 (c == b) -- in ONE workgroup with a fixed summation order
+// (bit-reproducible, unlike a library dot that picks its grid by size).
+namespace {
+__global__ __launch_bounds__(1024) void k_dot3(const double* a, const double* b, const double* c, int64_t n,
+                                               double* out) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s = fma(c ? a[i] * c[i] : a[i], b[i], s);
+    s = vt_sum64(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        out[0] = t;
+    }
+}
+}  // namespace
+
+extern "C" int vt_dot3(const double* a, const double* b, const double* c, int64_t n, double* out, void* stream) {
+    if (!out || n < 0 || (n > 0 && (!a || !b))) return VT_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_dot3, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, c, n, out);
+    return vt_launch_status();
+}

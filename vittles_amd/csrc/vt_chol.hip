@@ -553,16 +553,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
     }
 }
 
-int g_cu = 0;
-int num_cu() {
-    if (g_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        g_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return g_cu;
-}
+inline int num_cu() { return vt_num_cu(); }   // of the current device
 
 // Two waves per SIMD, one 16-row tile each: everything a wave keeps outside the
 // accumulator must fit the 256 architectural VGPRs, and the partner wave's MFMA

@@ -174,6 +174,16 @@ __host__ __device__ __forceinline__ constexpr int vt_tri(int a, int b) { return 
 
 // ---- internal (non-exported) entry points shared between translation units -------------------
 #include <algorithm>
+// Per-DEVICE host state (one process may drive several GPUs: `device=` is a public argument of the Python
+// layer).  vt_num_cu(): compute units of the CURRENT device (256 when no device is visible, so that the
+// workspace queries work on a CPU-only build host).  vt_allow_big_lds(): raise a kernel's dynamic-LDS limit
+// once per (call site, device) -- function attributes are per device.
+constexpr int VT_MAX_DEVICES = 64;
+struct VtLdsAttr {
+    bool done[VT_MAX_DEVICES] = {};
+};
+int vt_num_cu();
+int vt_allow_big_lds(const void* func, VtLdsAttr& flag, int bytes);
 int vt_potrf_pack_block(double* A, int lda, int D, int* info, double* pack, int do_factor, hipStream_t st);
 int vt_trsm_rows_mode(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
                       int64_t N, double* Out, int64_t ldo, int mode, hipStream_t st);

@@ -1,5 +1,6 @@
 // Library-level entry points: version, error strings, device probe.
 #include "vt_common.h"
+#include <atomic>
 
 extern "C" int vt_version(void) { return 101; }   // 101: global_terms argument of vt_vi_*
 
@@ -21,4 +22,26 @@ extern "C" int vt_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return VT_ERR_NO_DEVICE;
     return n;
+}
+
+int vt_num_cu() {
+    static std::atomic<int> cache[VT_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VT_MAX_DEVICES) return 256;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    v = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    cache[dev].store(v, std::memory_order_relaxed);
+    return v;
+}
+
+int vt_allow_big_lds(const void* func, VtLdsAttr& flag, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VT_MAX_DEVICES) return VT_ERR_HIP;
+    if (flag.done[dev]) return VT_OK;
+    if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return VT_ERR_HIP;
+    flag.done[dev] = true;
+    return VT_OK;
 }

@@ -762,16 +762,7 @@ __global__ __launch_bounds__(256) void k_hess_finalize(const double* in, int L, 
     }
 }
 
-int g_num_cu = 0;
-int num_cu() {
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return g_num_cu;
-}
+inline int num_cu() { return vt_num_cu(); }   // of the current device
 
 constexpr int kStage2 = 16;
 
@@ -794,20 +785,10 @@ void launch_hess_small2(const HessArgs& a, int grid, hipStream_t st) {
         hipLaunchKernelGGL((k_glm_hess_small<NB, FAM, false>), dim3(grid), dim3(512), 0, st, a);
 }
 
-// hipFuncSetAttribute is per device: one flag per (kernel instantiation, device)
-constexpr int kMaxDev = 64;
-
 template <int NB, int NS, int FAM>
 int launch_hess_tile3(const HessArgs& a, int grid, hipStream_t st) {
-    static bool attr_set[kMaxDev] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return VT_ERR_HIP;
-    if (!attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)k_glm_hess_tile<NB, NS, FAM>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return VT_ERR_HIP;
-        attr_set[dev] = true;
-    }
+    static VtLdsAttr attr;   // per kernel instantiation, per device
+    if (vt_allow_big_lds((const void*)k_glm_hess_tile<NB, NS, FAM>, attr, 160 * 1024) != VT_OK) return VT_ERR_HIP;
     hipLaunchKernelGGL((k_glm_hess_tile<NB, NS, FAM>), dim3(grid), dim3(kTileThreads), tile_lds_bytes(NB), st, a);
     return VT_OK;
 }

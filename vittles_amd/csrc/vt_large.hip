@@ -20,16 +20,7 @@ namespace {
 constexpr int kT = 128;            // tile / panel width
 constexpr int kPackStride = 2 * 36 * 256;   // doubles per diagonal-block pack (NB = 8)
 
-int g_cu = 0;
-int num_cu() {
-    if (g_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        g_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return g_cu;
-}
+inline int num_cu() { return vt_num_cu(); }   // of the current device
 
 // ------------------------------------------------------------------ GEMM NT -------
 struct GemmArgs {
@@ -234,6 +225,12 @@ __global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
         }
 }
 
+// dev switches, read ONCE per process (never on the hot path)
+static bool large_no_lds() {
+    static const bool v = getenv("VT_LARGE_NO_LDS") != nullptr;
+    return v;
+}
+
 static int large_stages() {
     // default 2: measured 48.6 vs 43.2 TFLOP/s (SYRK, N = 1.25e6, D = 1000); VT_LARGE_STAGES=3 for A/B runs
     static const int st = getenv("VT_LARGE_STAGES") ? atoi(getenv("VT_LARGE_STAGES")) : 2;
@@ -242,7 +239,7 @@ static int large_stages() {
 
 bool lds_path_ok(const double* A, int64_t lda, const double* B, int64_t ldb, int K) {
     return K % 2 == 0 && lda % 2 == 0 && ldb % 2 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
-           !getenv("VT_LARGE_NO_LDS");
+           !large_no_lds();
 }
 
 int gemm_nt(double* C, int64_t ldc, int64_t M, int N, const double* A, int64_t lda, const double* B,
@@ -254,16 +251,13 @@ int gemm_nt(double* C, int64_t ldc, int64_t M, int N, const double* A, int64_t l
     if (lds_path_ok(A, lda, B, ldb, K)) {
         const int stages = large_stages();
         const size_t shmem = (size_t)stages * 2 * (kKC / 2) * kT * 2 * sizeof(double);   // 96 / 64 KB
-        static bool attr_set = false;
-        if (!attr_set) {
-            const int mx = 3 * 2 * (kKC / 2) * kT * 2 * (int)sizeof(double);
-            if (hipFuncSetAttribute((const void*)k_gemm_nt_lds<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_gemm_nt_lds<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_gemm_nt_lds<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_gemm_nt_lds<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
-                return VT_ERR_HIP;
-            attr_set = true;
-        }
+        static VtLdsAttr attr[4];
+        const int mx = 3 * 2 * (kKC / 2) * kT * 2 * (int)sizeof(double);
+        if (vt_allow_big_lds((const void*)k_gemm_nt_lds<false, 3>, attr[0], mx) != VT_OK ||
+            vt_allow_big_lds((const void*)k_gemm_nt_lds<true, 3>, attr[1], mx) != VT_OK ||
+            vt_allow_big_lds((const void*)k_gemm_nt_lds<false, 2>, attr[2], mx) != VT_OK ||
+            vt_allow_big_lds((const void*)k_gemm_nt_lds<true, 2>, attr[3], mx) != VT_OK)
+            return VT_ERR_HIP;
         if (stages == 2) {
             if (lower) hipLaunchKernelGGL((k_gemm_nt_lds<true, 2>), grid, dim3(512), shmem, st, a);
             else hipLaunchKernelGGL((k_gemm_nt_lds<false, 2>), grid, dim3(512), shmem, st, a);
@@ -686,17 +680,12 @@ int vt_large_syrk(const double* X, int64_t ldx, const double* d, int64_t N, int 
     SyrkArgs a{X, ldx, d, N, D, nt, ks, (double*)ws, nullptr, 0, 0, 0};
     if (N == 0) {
         ks = 0;   // no rows: the reduce below sums zero slabs and adds the prior
-    } else if (ldx % 2 == 0 && (uintptr_t)X % 16 == 0 && !getenv("VT_LARGE_NO_LDS")) {
+    } else if (ldx % 2 == 0 && (uintptr_t)X % 16 == 0 && !large_no_lds()) {
         const size_t shmem = (size_t)large_stages() * 2 * kKC * (kT + 16) * sizeof(double);   // 108 / 72 KB
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)k_syrk_lds<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)shmem) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_syrk_lds<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)shmem) != hipSuccess)
-                return VT_ERR_HIP;
-            attr_set = true;
-        }
+        static VtLdsAttr attr[2];
+        if (vt_allow_big_lds((const void*)k_syrk_lds<false, 3>, attr[0], (int)shmem) != VT_OK ||
+            vt_allow_big_lds((const void*)k_syrk_lds<false, 2>, attr[1], (int)shmem) != VT_OK)
+            return VT_ERR_HIP;
         if (large_stages() == 2) hipLaunchKernelGGL((k_syrk_lds<false, 2>), dim3(ntl, ks), dim3(512), shmem, st, a);
         else hipLaunchKernelGGL((k_syrk_lds<false, 3>), dim3(ntl, ks), dim3(512), shmem, st, a);
     } else {
@@ -737,17 +726,12 @@ extern "C" int vt_gemm_tn(const double* A, int64_t lda, int Da, const double* B,
     SyrkArgs a{A, lda, rowscale, N, Da, nta, ks, (double*)ws, B, ldb, Db, ntb};
     if (N == 0) {
         ks = 0;   // no rows: C = bias
-    } else if (lda % 2 == 0 && ldb % 2 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0 && !getenv("VT_LARGE_NO_LDS")) {
+    } else if (lda % 2 == 0 && ldb % 2 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0 && !large_no_lds()) {
         const size_t shmem = (size_t)large_stages() * 2 * kKC * (kT + 16) * sizeof(double);   // 108 / 72 KB
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)k_syrk_lds<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)shmem) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_syrk_lds<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)shmem) != hipSuccess)
-                return VT_ERR_HIP;
-            attr_set = true;
-        }
+        static VtLdsAttr attr[2];
+        if (vt_allow_big_lds((const void*)k_syrk_lds<true, 3>, attr[0], (int)shmem) != VT_OK ||
+            vt_allow_big_lds((const void*)k_syrk_lds<true, 2>, attr[1], (int)shmem) != VT_OK)
+            return VT_ERR_HIP;
         if (large_stages() == 2) hipLaunchKernelGGL((k_syrk_lds<true, 2>), dim3(ntl, ks), dim3(512), shmem, st, a);
         else hipLaunchKernelGGL((k_syrk_lds<true, 3>), dim3(ntl, ks), dim3(512), shmem, st, a);
     } else {

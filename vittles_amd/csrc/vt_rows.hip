@@ -409,16 +409,7 @@ __global__ __launch_bounds__(1024) void k_rows_finalize(const double* part, int 
     }
 }
 
-int g_cu = 0;
-int num_cu() {
-    if (g_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        g_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return g_cu;
-}
+inline int num_cu() { return vt_num_cu(); }   // of the current device
 
 struct RowCfg {
     int team, cpt, vec, wg, teams;
@@ -464,13 +455,8 @@ void launch_one(const RowArgs& a, int grid, bool nt, hipStream_t st) {
 template <int OP, int VEC, int CPT, int P>
 int launch_wide(const RowArgs& a, int grid, hipStream_t st) {
     size_t shmem = (size_t)8 * (((a.D + 1) & ~1) + 2 + 2 * (kWideTeam / 64));
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_rows_wide<OP, VEC, CPT, P>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return VT_ERR_HIP;
-        attr_set = true;
-    }
+    static VtLdsAttr attr;  // per instantiation, per device
+    if (vt_allow_big_lds((const void*)k_rows_wide<OP, VEC, CPT, P>, attr, 160 * 1024) != VT_OK) return VT_ERR_HIP;
     hipLaunchKernelGGL((k_rows_wide<OP, VEC, CPT, P>), dim3(grid), dim3(kWideTeam), shmem, st, a);
     return VT_OK;
 }

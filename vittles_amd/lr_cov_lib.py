@@ -65,12 +65,12 @@ class LinearResponseCovariances:
         """2-norm over the WHOLE parameter vector: for a sharded objective the local entries of every rank plus
         the replicated globals once."""
         if self._group is None:
-            return float(torch.linalg.vector_norm(vec).item())
+            return rows.norm(vec)
         from . import sharding
         nl = vec.shape[0] - self._n_global
-        sq = (vec[:nl] * vec[:nl]).sum().reshape(1)
+        sq = rows.dot(vec[:nl], vec[:nl])
         sharding.all_reduce_sum(sq, self._group)
-        return float((sq[0] + (vec[nl:] * vec[nl:]).sum()).sqrt().item())
+        return float((sq + rows.dot(vec[nl:], vec[nl:])).sqrt().item())
 
     def get_hessian_at_opt(self):
         return self._hess0

@@ -117,8 +117,13 @@ class WeightedGLMObjective(RegisteredObjective):
         nbytes = lib.vt_glm_hessian_workspace_bytes(self.N, self.D)
         if nbytes == 0:
             raise _lib.VittlesHipError("vt_glm_hessian does not support D = %d" % self.D)
-        if self._ws is None or self._ws.numel() * 8 < nbytes:
-            self._ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=self.device)
+        # scratch per stream: two streams driving one objective never share it
+        skey = dev.stream_ptr()
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(skey)
+        if ws is None or ws.numel() * 8 < nbytes:
+            ws = self._ws[skey] = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=self.device)
         # H and g are views of ONE buffer, so that the row-sharded path all-reduces a single
         # message of D*D + D doubles in place (no gather / scatter copies around the collective)
         # (g starts on a 256-byte boundary; the few padding doubles in between ride along)
@@ -133,7 +138,7 @@ class WeightedGLMObjective(RegisteredObjective):
             _lib.FAMILY[self.family], self.X.data_ptr(), dev.ld(self.X), theta.data_ptr(),
             self.y.data_ptr(), w.data_ptr(), dev.ptr(self.offset), self.scale, dev.ptr(prior),
             self.N, self.D, H.data_ptr(), self.D, g.data_ptr(), r.data_ptr(), d.data_ptr(),
-            self._ws.data_ptr(), self._ws.numel() * 8, dev.stream_ptr()), "vt_glm_hessian")
+            ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_glm_hessian")
         if self.stage_hook is not None:
             self.stage_hook("allreduce_begin")
         self._all_reduce(Hg)          # one RCCL message: D*D + D doubles

@@ -10,7 +10,7 @@ all-reduced exactly as on the sensitivity path, so every rank takes identical st
 """
 import torch
 
-from . import device as dev, sharding
+from . import device as dev, rows, sharding
 from .linalg import DeviceCholesky
 from .objectives import WeightedGLMObjective
 
@@ -51,15 +51,14 @@ def newton_glm(objective, hyper_par, opt_par_init=None, max_iter=50, grad_tol=1e
     for it in range(1, max_iter + 1):
         out = objective.fused(theta, w)                     # K0 + K1 + K3 (+ all-reduce)
         g, H = out["g"], out["H"]
-        (gnorm,) = agree(float(torch.linalg.vector_norm(g).item()))
+        (gnorm,) = agree(rows.norm(g))
         if gnorm <= grad_tol:
             converged = True
             it -= 1
             break
         step = DeviceCholesky.factor(H, pack=True).solve(g)  # K4 + K5; LinAlgError if H is not PD
-        slope, step_norm, theta_norm = agree(float(torch.dot(g, step).item()),            # slope > 0 for PD H
-                                             float(torch.linalg.vector_norm(step).item()),
-                                             float(torch.linalg.vector_norm(theta).item()))
+        slope, step_norm, theta_norm = agree(float(rows.dot(g, step).item()),            # slope > 0 for PD H
+                                             rows.norm(step), rows.norm(theta))
         # objective values carry rounding noise of a few ulps of |f|: once the predicted decrease
         # is below it the value test says nothing, and the full Newton step is taken
         noise = 64.0 * 2.2e-16 * max(1.0, abs(value))
@@ -77,7 +76,7 @@ def newton_glm(objective, hyper_par, opt_par_init=None, max_iter=50, grad_tol=1e
         theta, value = cand, cand_value
         if snorm <= step_tol * max(1.0, theta_norm):
             out = objective.fused(theta, w)
-            (gnorm,) = agree(float(torch.linalg.vector_norm(out["g"]).item()))
+            (gnorm,) = agree(rows.norm(out["g"]))
             converged = gnorm <= max(grad_tol, 1e-6)
             break
     info = dict(iterations=it, grad_norm=gnorm, value=value, converged=converged, halvings=halvings_total)

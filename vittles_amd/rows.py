@@ -7,14 +7,35 @@ _ws_cache = {}
 
 
 def _workspace(D, device):
+    """Scratch of the row-streaming kernels, one buffer per (device, STREAM, size): two streams of one process
+    never share scratch (kernels on different streams may overlap)."""
     lib = dev.require_gpu()
     nbytes = lib.vt_rows_workspace_bytes(int(D))
-    key = (device.index, nbytes)
+    key = (device.index, dev.stream_ptr(), nbytes)
     ws = _ws_cache.get(key)
     if ws is None:
         ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
         _ws_cache[key] = ws
     return ws
+
+
+def dot(a, b, c=None):
+    """sum_i a_i b_i (c_i) of CUDA fp64 vectors as a 1-element CUDA tensor (fixed-order, one launch)."""
+    lib = dev.require_gpu()
+    a, b = a.contiguous().reshape(-1), b.contiguous().reshape(-1)
+    if a.shape != b.shape or (c is not None and c.shape != a.shape):
+        raise ValueError("dot: shapes differ")
+    if c is not None:
+        c = c.contiguous().reshape(-1)
+    out = torch.empty(1, dtype=torch.float64, device=a.device)
+    _lib.check(lib.vt_dot3(a.data_ptr(), b.data_ptr(), dev.ptr(c), a.shape[0], out.data_ptr(), dev.stream_ptr()),
+               "vt_dot3")
+    return out
+
+
+def norm(a):
+    """2-norm of a CUDA fp64 vector as a Python float."""
+    return float(dot(a, a).sqrt().item())
 
 
 def _rowmajor(A):
@@ -72,11 +93,12 @@ def glm_taylor2_rhs(obj, z, w, dw, u):
     return out
 
 
-def glm_taylor3_rhs(obj, z, w, dw, d1, d2):
-    """Third-order data-weight right-hand side of a WeightedGLMObjective: one pass for zeta2 = X d2,
-    one fused pass for the sum (see include/vittles_hip.h)."""
+def glm_taylor3_rhs(obj, z, w, dw, d1, d2=None, zeta2=None):
+    """Third-order data-weight right-hand side of a WeightedGLMObjective: one pass for zeta2 = X d2
+    (unless ``zeta2`` is given), one fused pass for the sum (see include/vittles_hip.h)."""
     lib = dev.require_gpu()
-    zeta2 = gemv(obj.X, d2)
+    if zeta2 is None:
+        zeta2 = gemv(obj.X, d2)
     out = torch.empty(obj.D, dtype=torch.float64, device=obj.device)
     ws = _workspace(obj.D, obj.device)
     _lib.check(lib.vt_glm_taylor3_rhs(_lib.FAMILY[obj.family], obj.X.data_ptr(), dev.ld(obj.X), z.data_ptr(),
@@ -101,11 +123,12 @@ def gemm_tn(A, B, rowscale=None, alpha=1.0, bias=None, out=None):
     nbytes = lib.vt_gemm_tn_workspace_bytes(Da, Db)
     if nbytes == 0:
         raise _lib.VittlesHipError("vt_gemm_tn does not support a (%d, %d) product" % (Da, Db))
-    key = (A.device.index, nbytes)
+    key = (A.device.index, dev.stream_ptr(), nbytes)
     ws = _tn_ws_cache.get(key)
     if ws is None:
         ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=A.device)
-        _tn_ws_cache.clear()          # one live workspace per process is enough
+        for k in [k for k in _tn_ws_cache if k[:2] == key[:2]]:   # one live workspace per (device, stream)
+            del _tn_ws_cache[k]
         _tn_ws_cache[key] = ws
     if out is None:
         out = torch.empty((Da, Db), dtype=torch.float64, device=A.device)
@@ -173,5 +196,5 @@ def glm_value(obj, theta, w):
     obj._all_reduce(val)
     total = float(val.item())
     if obj.prior is not None:
-        total += 0.5 * float((obj.prior * theta * theta).sum().item())
+        total += 0.5 * float(dot(obj.prior, theta, theta).item())
     return total

@@ -81,6 +81,9 @@ def _len(x):
 
 
 def _norm(x):
+    if isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float64:
+        from . import rows
+        return rows.norm(x)
     if isinstance(x, torch.Tensor):
         return float(torch.linalg.vector_norm(x).item())
     return float(np.linalg.norm(x))
@@ -307,9 +310,13 @@ class ParametricSensitivityTaylorExpansion:
         d1 = -H^{-1} X^T (r .* dw)
         d2 = -H^{-1} X^T scale (w ell''' t^2 + 2 dw ell'' t),   t = X d1
 
-    Same constructor / classmethod arguments and methods as the reference; ``forward_mode``,
-    ``max_input_order``, ``max_hyper_order`` and ``force`` are accepted (the closed forms make
-    them moot: the objective is linear in the weights, so hyper-order is 1 by construction)."""
+        d3 = -H^{-1} X^T scale (w (l4 t^3 + 3 l3 t t2) + 3 dw (l3 t^2 + l2 t2)),   t2 = X d2, lk = k-th link derivative
+
+    Same constructor / classmethod arguments and methods as the reference.  ``max_input_order`` truncates
+    like the reference does (:1242-1249: a term whose number of partial derivatives w.r.t. the input exceeds it
+    is dropped): with 1 only the ``dw l2`` terms survive, with 2 the ``l4`` term goes.  The objective
+    is linear in the weights, so every term has hyper order <= 1 and ``max_hyper_order`` >= 1 changes nothing;
+    ``forward_mode`` and ``force`` are accepted and moot."""
 
     @classmethod
     def optimization_objective(cls, objective_function, input_val0, hyper_val0, order, hess0=None,
@@ -383,12 +390,28 @@ class ParametricSensitivityTaylorExpansion:
         if len(input_derivs) < k - 1:
             raise ValueError('Not enough eta_derivs provided.')
         obj = self._obj
+        # terms with more than ``max_input_order`` partial derivatives w.r.t. the input are dropped
+        # (reference :1247-1249); the gaussian family has none beyond order 1
+        mio = self._max_input_order if self._max_input_order is not None else k
         if k == 1:
             vec = rows.gemv_t2(obj.X, self._r, dhyper)
         elif k == 2:
-            vec = rows.glm_taylor2_rhs(obj, self._z, self._w, dhyper, input_derivs[0])
+            # G_tt[d1, d1] (input order 2: the w l3 t^2 part) + 2 G_tw[d1, dw] (input order 1)
+            w_eff = self._w if mio >= 2 else torch.zeros_like(self._w)
+            vec = rows.glm_taylor2_rhs(obj, self._z, w_eff, dhyper, input_derivs[0])
         elif k == 3 and obj.family != 'gaussian':
-            vec = rows.glm_taylor3_rhs(obj, self._z, self._w, dhyper, input_derivs[0], input_derivs[1])
+            # A = w l4 t^3 (input order 3), B = 3 w l3 t t2 and C = 3 dw l3 t^2 (order 2), E = 3 dw l2 t2
+            # (order 1); the kernel returns A + B + C + E for the inputs it is given
+            d1, d2 = input_derivs[0], input_derivs[1]
+            zero_n = torch.zeros_like(self._w)
+            if mio >= 3:
+                vec = rows.glm_taylor3_rhs(obj, self._z, self._w, dhyper, d1, d2)
+            elif mio == 2:      # everything but A = kernel(w, dw = 0, t2 = 0)
+                vec = rows.glm_taylor3_rhs(obj, self._z, self._w, dhyper, d1, d2) - \
+                    rows.glm_taylor3_rhs(obj, self._z, self._w, zero_n, d1, zeta2=zero_n)
+            else:               # E alone = kernel(0, dw, t2) - kernel(0, dw, 0)
+                vec = rows.glm_taylor3_rhs(obj, self._z, zero_n, dhyper, d1, d2) - \
+                    rows.glm_taylor3_rhs(obj, self._z, zero_n, dhyper, d1, zeta2=zero_n)
         else:
             # gaussian family: G is bilinear in (theta, w), so the order-k equation is
             # H d_k + k (d^2 G / d theta d w)[d_{k-1}, dw] = 0: one fused pass X^T (scale dw .* (X d_{k-1}))
@@ -432,6 +455,34 @@ class ParametricSensitivityTaylorExpansion:
             fact *= k
             terms.append(d / fact)
         return [dev.like_input(t, self._input_val0) for t in terms]
+
+    def print_terms(self, k=None):
+        """Print the derivative terms of the series (reference :1346-1363), in the reference's format
+        ``Order: o\tprefactor * eta[orders] * eps[order]``, for the terms this build evaluates."""
+        if k is not None and k > self._order:
+            raise ValueError('k must be no greater than order={}'.format(self._order))
+        nonlin = self._obj.family != 'gaussian'
+        # (prefactor, eta_orders, eps_order) of the terms of d^k G / d eps^k = 0 that do not vanish for an
+        # objective linear in the weights; eta_orders[j] = how many factors d^{j+1} eta the term carries
+        table = {1: [(1, [1], 0), (1, [0], 1)],
+                 2: [(1, [0, 1], 0), (2, [1, 0], 1)] + ([(1, [2, 0], 0)] if nonlin else []),
+                 3: [(1, [0, 0, 1], 0), (3, [0, 1, 0], 1)] +
+                    ([(1, [3, 0, 0], 0), (3, [1, 1, 0], 0), (3, [2, 0, 0], 1)] if nonlin else [])}
+        for order in range(self._order):
+            if k is None or order == (k - 1):
+                print('\nTerms for order {}:'.format(order + 1))
+                terms = table.get(order + 1)
+                if terms is None:       # gaussian family, order > 3: H d_k + k G_tw[d_{k-1}, dw]
+                    eta = [0] * (order + 1)
+                    eta[order] = 1
+                    eta2 = [0] * (order + 1)
+                    eta2[order - 1] = 1
+                    terms = [(1, eta, 0), (order + 1, eta2, 1)]
+                for pre, eta_orders, eps_order in terms:
+                    if self._max_input_order is not None and sum(eta_orders) > self._max_input_order \
+                            and eta_orders[-1] == 0:
+                        continue
+                    print('Order: {}\t{} * eta{} * eps[{}]'.format(order + 1, pre, eta_orders, eps_order))
 
     def evaluate_taylor_series(self, new_hyper_val, add_offset=True, max_order=None, sum_terms=True):
         # Reference :1303-1342 (which sums the terms whatever ``sum_terms`` says).
