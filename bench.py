@@ -51,6 +51,7 @@ def parse():
     p.add_argument("--cg-cpu-rows", type=int, default=4_000)
     p.add_argument("--no-block", action="store_true", help="skip the block-sparse VI side measurement (configs[4])")
     p.add_argument("--block-groups", type=int, default=10_000)
+    p.add_argument("--no-fp32", action="store_true", help="skip the fp32 storage-mode side measurement (row n1)")
     return p.parse_args()
 
 
@@ -325,6 +326,63 @@ def config1_side_measurement(torch):
             "os_cpu_count": os.cpu_count(), "S_max_rel_err_gpu_vs_ad": err}
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+def fp32_side_measurement(torch, va, DeviceCholesky, X, y, w, theta, prior, H64, S64, reps=200):
+    """the same pipeline with X and S stored in float (optional mode, tolerance
+    1e-4 against fp64, NEVER the headline `value`).  Parity is taken against this run's fp64 H and S."""
+    N, D = X.shape
+    X32 = X.to(torch.float32)
+    obj = va.WeightedGLMObjective(X32, y, family="logistic", prior=prior, dtype=torch.float32)
+    S32 = torch.empty((N, D), dtype=torch.float32, device=X.device)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+
+    def step(i=None):
+        obj.invalidate_cache()
+        if i is not None:
+            ev[i][0].record()
+        out = obj.fused(theta, w)
+        if i is not None:
+            ev[i][1].record()
+        chol = DeviceCholesky.factor(out["H"], check=False, pack=True)
+        chol.pack32()
+        if i is not None:
+            ev[i][2].record()
+        chol.solve_rows(X32, rowscale=out["r"], alpha=-1.0, out=S32)
+        if i is not None:
+            ev[i][3].record()
+        return out
+    for _ in range(100):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(reps):
+        out = step(i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    ms_h = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    ms_c = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    ms_t = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+    res = {"note": "optional fp32 STORAGE mode (X and S float; link, r, d, H, g, Cholesky double): reduced precision, "
+                   "reported beside the fp64 headline, never as `value`",
+           "dtype": "f32 storage / f32 MFMA products / fp64 sums", "ms_per_step": ms,
+           "sensitivities_per_s": N / (ms * 1e-3),
+           "stages_ms": {"fused_link_grad_hessian": ms_h, "cholesky_pack": ms_c, "sens_trsm": ms_t},
+           "hessian_TFLOPs_triangle": float(N) * D * (D + 1) / (ms_h * 1e-3) / 1e12,
+           "trsm_TFLOPs": 2.0 * D * D * N / (ms_t * 1e-3) / 1e12,
+           "trsm_hbm_GBs": (8.0 * N * D + 8.0 * N) / (ms_t * 1e-3) / 1e9,
+           "fp32_mfma_peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS,
+           "tolerance": 1e-4,
+           "H_max_rel_err_vs_fp64": float(((out["H"] - H64).abs().max() / H64.abs().max()).item())}
+    err = 0.0
+    smax = float(S64.abs().max().item())
+    for a in range(0, N, 1 << 18):     # in slabs: no second N x D fp64 temporary
+        err = max(err, float((S32[a:a + (1 << 18)].double() - S64[a:a + (1 << 18)]).abs().max().item()))
+    res["S_max_rel_err_vs_fp64"] = err / smax
+    return res
+
+
 def note(msg):
     if os.environ.get("VITTLES_BENCH_VERBOSE"):
         print("[bench rank %s %.1fs] %s" % (os.environ.get("RANK", "0"), time.perf_counter(), msg),
@@ -555,6 +613,9 @@ def main():
                 del Xh, H_cpu, S_cpu
                 result["speedup_vs_cpu_baseline"] = value / base["value"]
                 result["config1"] = config1_side_measurement(torch)
+            if not args.no_fp32 and D <= 128:
+                result["fp32_mode"] = fp32_side_measurement(torch, va, DeviceCholesky, X, y, w, theta, prior,
+                                                            out["H"], S)
             del S, X
             torch.cuda.empty_cache()
             if not args.no_hvp:

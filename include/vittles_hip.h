@@ -231,6 +231,46 @@ int    vt_glm_value(int family, const double* X_dev, int64_t ldx, const double* 
                     const double* y_dev, const double* w_dev, const double* offset_dev, double scale,
                     int64_t N, int D, double* value_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* ---- fp32 STORAGE mode (BASELINE.json north_star: "optional fp32 mode", 1e-4 against the fp64 oracle) ------
+ * The two N x D arrays that set the HBM traffic -- X and the sensitivity matrix S -- are float; theta, y, w,
+ * offset, the per-row factors r and d, H, g, the Cholesky factor and every D-vector stay double.  Row sums are
+ * carried in fp64; the two MFMA kernels multiply in f32 (v_mfma_f32_16x16x4_f32) and fold their f32 accumulators
+ * into fp64 every <= 4096 rows.  D <= VT_SMALL_D_MAX for the Hessian / TRSM, D <= 4096 for the row operators;
+ * anything larger returns VT_ERR_UNSUPPORTED (use the fp64 entry points).  Each entry point replaces the same
+ * reference lines as its fp64 namesake above and takes the same arguments, with float where noted. */
+size_t vt_glm_hessian_f32_workspace_bytes(int64_t N, int D);
+int    vt_glm_hessian_f32(int family, const float* X_dev, int64_t ldx, const double* theta_dev,
+                          const double* y_dev, const double* w_dev, const double* offset_dev, double scale,
+                          const double* prior_dev, int64_t N, int D, double* H_dev, int ldh, double* g_dev,
+                          double* r_dev, double* d_dev, void* ws_dev, size_t ws_bytes, void* stream);
+/* pack32_dev (vt_trsm_pack_f32_bytes(D) bytes) <- the operand pack of vt_potrf_pack / vt_trsm_pack (the
+ * factorisation itself is always fp64), rounded to float and laid out for the f32 MFMA chain. */
+size_t vt_trsm_pack_f32_bytes(int D);
+int    vt_trsm_pack_f32(const void* pack_dev, int D, void* pack32_dev, void* stream);
+/* Out[n, :] = alpha * rowscale[n] * (L L^T)^{-1} B[n, :]  with float B and Out (rowscale stays double). */
+int    vt_trsm_rows_f32(const void* pack32_dev, int D, const float* B_dev, int64_t ldb,
+                        const double* rowscale_dev, double alpha, int64_t N, float* Out_dev, int64_t ldo,
+                        void* stream);
+/* the row operators (workspace: vt_rows_workspace_bytes(D), as for the fp64 ones) */
+int    vt_glm_link_f32(int family, const float* X_dev, int64_t ldx, const double* theta_dev,
+                       const double* y_dev, const double* w_dev, const double* offset_dev, double scale,
+                       int64_t N, int D, double* z_dev, double* r_dev, double* d_dev, void* ws_dev,
+                       size_t ws_bytes, void* stream);
+int    vt_glm_grad_f32(int family, const float* X_dev, int64_t ldx, const double* theta_dev,
+                       const double* y_dev, const double* w_dev, const double* offset_dev, double scale,
+                       const double* prior_dev, int64_t N, int D, double* g_dev, double* r_dev, double* d_dev,
+                       void* ws_dev, size_t ws_bytes, void* stream);
+int    vt_glm_hvp_f32(const float* X_dev, int64_t ldx, const double* d_dev, const double* prior_dev,
+                      double prior_scalar, const double* v_dev, int64_t N, int D, double* out_dev, void* ws_dev,
+                      size_t ws_bytes, void* stream);
+int    vt_gemv_t_f32(const float* A_dev, int64_t lda, const double* u_dev, int64_t N, int D, double* out_dev,
+                     void* ws_dev, size_t ws_bytes, void* stream);
+int    vt_gemv_f32(const float* A_dev, int64_t lda, const double* v_dev, int64_t N, int D, double* out_dev,
+                   void* ws_dev, size_t ws_bytes, void* stream);
+int    vt_glm_value_f32(int family, const float* X_dev, int64_t ldx, const double* theta_dev,
+                        const double* y_dev, const double* w_dev, const double* offset_dev, double scale,
+                        int64_t N, int D, double* value_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
 /* ---- K6 driver: the BLAS-1 part of one CG iteration, fused into one launch -------------
  * Replaces: the loop body of scipy.sparse.linalg.cg as called by
  *             vittles/solver_lib.py:91-97 (SciPy _isolve/iterative.py: rho = r.r;

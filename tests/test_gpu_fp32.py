@@ -1,0 +1,223 @@
+"""GPU parity of the optional fp32 STORAGE mode (BASELINE.json north_star: "optional
+fp32 mode", 1e-4 against the fp64 oracle).  X and the sensitivity matrix are float, everything else double.
+
+Two bars per result:
+  * MODE  = 1e-4 against the oracle on the caller's fp64 X (the tolerance north_star states);
+  * what the arithmetic actually promises against the oracle on X ROUNDED to float: the row operators carry
+    every sum in fp64 (1e-12), the MFMA kernels multiply in f32 and fold into fp64 every 4096 rows (1e-5).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MODE = 1e-4      # north_star's fp32-mode tolerance
+F32 = 1e-5       # f32 MFMA products, chunked fp64 accumulation
+EXACT = 1e-12    # fp64 sums of float data
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _problem(N, D, family, seed, with_offset=False):
+    from oracle import glm
+    X, y, w, _ = glm.synth(N, D, family, seed)
+    rng = np.random.default_rng(seed + 100)
+    w = 0.5 + rng.random(N)
+    theta = rng.standard_normal(D) / np.sqrt(D)
+    offset = 0.1 * rng.standard_normal(N) if with_offset else None
+    return X, y, w, theta, offset
+
+
+@pytest.mark.parametrize("N,D", [(1, 1), (3, 5), (17, 16), (1000, 20), (257, 31), (4099, 32), (2000, 100),
+                                 (513, 128), (1001, 97), (300, 113), (5003, 77), (20001, 100), (6001, 127),
+                                 (40000, 81), (33000, 65)])
+@pytest.mark.parametrize("family", ["logistic", "poisson", "gaussian"])
+def test_fp32_fused_hessian_grad(N, D, family, relerr):
+    torch = _torch()
+    from oracle import glm
+    import vittles_amd as va
+    X, y, w, theta, offset = _problem(N, D, family, seed=N + D, with_offset=(D % 2 == 0))
+    prior = np.linspace(0.5, 2.0, D)
+    scale = 1.5
+    obj = va.WeightedGLMObjective(X, y, family=family, prior=prior, scale=scale, offset=offset,
+                                  dtype=torch.float32)
+    assert obj.X.dtype == torch.float32
+    out = obj.fused(theta, w)
+    H, g = out["H"].cpu().numpy(), out["g"].cpu().numpy()
+    assert out["H"].dtype == torch.float64 and np.array_equal(H, H.T)
+    X32 = X.astype(np.float32).astype(np.float64)
+    # against the oracle on the rounded X: r and d are fp64 row dots of float data
+    _, l1, l2 = glm.link(family, glm.linear_predictor(X32, theta, offset), y)
+    assert relerr(out["r"].cpu().numpy(), scale * l1) < EXACT
+    assert relerr(out["d"].cpu().numpy(), scale * w * l2) < EXACT
+    assert relerr(H, glm.hessian(family, X32, y, theta, w, prior, scale, offset)) < F32
+    assert relerr(g, glm.grad(family, X32, y, theta, w, prior, scale, offset)) < F32
+    # against the oracle on the caller's X: the mode's stated tolerance
+    assert relerr(H, glm.hessian(family, X, y, theta, w, prior, scale, offset)) < MODE
+    assert relerr(g, glm.grad(family, X, y, theta, w, prior, scale, offset)) < MODE
+
+
+def test_fp32_hessian_empty_and_prior_only(relerr):
+    torch = _torch()
+    import vittles_amd as va
+    D = 7
+    prior = np.linspace(1.0, 2.0, D)
+    theta = np.arange(D) / 10.0
+    obj = va.WeightedGLMObjective(np.zeros((0, D)), np.zeros(0), prior=prior, dtype=torch.float32)
+    out = obj.fused(theta, np.zeros(0))
+    assert relerr(out["H"].cpu().numpy(), np.diag(prior)) == 0.0
+    assert relerr(out["g"].cpu().numpy(), prior * theta) == 0.0
+
+
+def test_fp32_hessian_chunked_accumulation(relerr):
+    """More than 4096 rows per wave: the f32 accumulators are folded into the fp64 slab several times
+    (one-wave-per-SIMD kernel, NB = 6: 1024 waves x 4096 rows = 4.2 M rows per fold).  Compared with the fp64
+    kernel on the same (float-representable) data; sizes beyond what the CPU oracle does in seconds."""
+    torch = _torch()
+    import vittles_amd as va
+    N, D = 9_000_000, 90
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    X32 = torch.randn((N, D), generator=gen, device="cuda", dtype=torch.float32)
+    theta = torch.randn(D, generator=gen, device="cuda", dtype=torch.float64) / D ** 0.5
+    y = (torch.rand(N, generator=gen, device="cuda", dtype=torch.float64) < 0.5).to(torch.float64)
+    w = 0.5 + torch.rand(N, generator=gen, device="cuda", dtype=torch.float64)
+    o32 = va.WeightedGLMObjective(X32, y, prior=1.0, dtype=torch.float32).fused(theta, w)
+    H32, g32 = o32["H"].cpu().numpy(), o32["g"].cpu().numpy()
+    d32 = o32["d"][::1001].cpu().numpy()
+    del o32
+    o64 = va.WeightedGLMObjective(X32.to(torch.float64), y, prior=1.0).fused(theta, w)
+    assert relerr(d32, o64["d"][::1001].cpu().numpy()) < EXACT
+    assert relerr(H32, o64["H"].cpu().numpy()) < F32
+    assert relerr(g32, o64["g"].cpu().numpy()) < MODE   # the gradient is a sum of signed terms near an optimum-free theta
+
+
+def test_fp32_trsm_identity_layout():
+    """H = I with an ASYMMETRIC integer right-hand side: the solve must return B element for element
+    (catches any row / column swap in the f32 operand maps and in the pack conversion)."""
+    torch = _torch()
+    from vittles_amd.linalg import DeviceCholesky
+    for D in (1, 16, 20, 100, 113, 128):
+        chol = DeviceCholesky.factor(torch.eye(D, dtype=torch.float64, device="cuda"))
+        B = (torch.arange(70 * D, dtype=torch.float32, device="cuda").reshape(70, D) + 1.0)
+        out = chol.solve_rows(B)
+        assert out.dtype == torch.float32
+        assert torch.equal(out, B), D
+
+
+@pytest.mark.parametrize("D", [1, 5, 16, 31, 48, 77, 100, 128])
+def test_fp32_trsm_rows(D, relerr):
+    torch = _torch()
+    from vittles_amd.linalg import DeviceCholesky
+    rng = np.random.default_rng(D)
+    A = rng.standard_normal((D + 5, D))
+    H = A.T @ A / D + np.eye(D)
+    N = 1000 + D
+    B = rng.standard_normal((N, D)).astype(np.float32)
+    s = 0.5 + rng.random(N)
+    chol = DeviceCholesky.factor(torch.tensor(H, device="cuda"))
+    got = chol.solve_rows(torch.tensor(B, device="cuda"), rowscale=torch.tensor(s, device="cuda"), alpha=-2.0)
+    ref = -2.0 * s[:, None] * np.linalg.solve(H, B.astype(np.float64).T).T
+    assert got.dtype == torch.float32 and got.shape == (N, D)
+    assert relerr(got.cpu().numpy(), ref) < F32 * 10
+
+
+@pytest.mark.parametrize("N,D", [(1, 3), (16, 16), (33, 20), (1000, 20), (4099, 100), (777, 128), (500, 45)])
+@pytest.mark.parametrize("family", ["logistic", "gaussian"])
+def test_fp32_sensitivity_end_to_end(N, D, family, relerr):
+    """The drop-in class in fp32 mode against the fp64 oracle (reference sensitivity_lib.py:226), 1e-4."""
+    torch = _torch()
+    from oracle import glm
+    import vittles_amd as va
+    X, y, w, _, _ = _problem(N, D, family, seed=7 * N + D)
+    prior = 1.0
+    theta = glm.newton_optimum(family, X, y, w, prior=prior)
+    obj = va.WeightedGLMObjective(X, y, family=family, prior=prior, dtype=torch.float32)
+    sens = va.HyperparameterSensitivityLinearApproximation(obj, theta, w)
+    H, jac0, S = glm.sensitivity(family, X, y, theta, w, prior=prior)
+    got = sens.get_dopt_dhyper()
+    assert got.shape == (D, N) and got.dtype == np.float32
+    assert relerr(got, S) < MODE
+    assert relerr(sens.get_hessian_at_opt(), H) < MODE
+    w1 = w * (1.0 + 0.01 * np.cos(np.arange(N)))
+    pred = sens.predict_opt_par_from_hyper_par(w1)
+    assert pred.dtype == np.float64
+    assert relerr(pred, theta + S @ (w1 - w)) < MODE
+    # validate_optimum: the gradient of the ROUNDED problem at the fp64 optimum is ~1e-7 N, not 1e-8
+    va.HyperparameterSensitivityLinearApproximation(obj, theta, w, validate_optimum=True, grad_tol=1e-3 * N)
+
+
+def test_fp32_row_operators(relerr):
+    """K0 link, K3 gradient, K6 HVP, K9 A^T u, A v, value on float X: fp64 sums of float data, so they agree
+    with the oracle on the rounded X to fp64 accuracy."""
+    torch = _torch()
+    from oracle import glm
+    from vittles_amd import rows
+    import vittles_amd as va
+    for (N, D, family) in [(1000, 20, "logistic"), (513, 129, "poisson"), (3000, 1000, "gaussian"),
+                           (257, 31, "logistic"), (64, 4096, "logistic"), (5000, 100, "poisson")]:
+        X, y, w, theta, offset = _problem(N, D, family, seed=N + D, with_offset=True)
+        if family == "poisson":
+            theta = theta * 0.1
+        X32 = X.astype(np.float32).astype(np.float64)
+        prior = np.linspace(0.5, 2.0, D)
+        obj = va.WeightedGLMObjective(X, y, family=family, prior=prior, scale=0.7, offset=offset,
+                                      dtype=torch.float32)
+        th, wd = torch.tensor(theta, device="cuda"), torch.tensor(w, device="cuda")
+        z, r, d = rows.glm_link(obj, th, wd, want_z=True)
+        zr = glm.linear_predictor(X32, theta, offset)
+        _, l1, l2 = glm.link(family, zr, y)
+        assert relerr(z.cpu().numpy(), zr) < EXACT
+        assert relerr(r.cpu().numpy(), 0.7 * l1) < EXACT
+        g, _, d2 = rows.glm_grad(obj, th, wd, prior=obj.prior)
+        assert relerr(g.cpu().numpy(), glm.grad(family, X32, y, theta, w, prior, 0.7, offset)) < 1e-11
+        v = np.cos(np.arange(D))
+        hv = rows.glm_hvp(obj.X, d2, torch.tensor(v, device="cuda"), prior=obj.prior)
+        assert relerr(hv.cpu().numpy(), glm.hvp(family, X32, y, theta, w, v, prior, 0.7, offset)) < 1e-11
+        u = np.sin(np.arange(N))
+        assert relerr(rows.gemv_t(obj.X, torch.tensor(u, device="cuda")).cpu().numpy(), X32.T @ u) < 1e-11
+        assert relerr(rows.gemv(obj.X, torch.tensor(v, device="cuda")).cpu().numpy(), X32 @ v) < EXACT
+        val = obj(theta, w)
+        ref = glm.value(family, X32, y, theta, w, prior, 0.7, offset)
+        assert abs(val - ref) <= 1e-11 * abs(ref)
+
+
+def test_fp32_newton_fit(relerr):
+    """The optimiser runs on the float X (gradient / Hessian / value through the *_f32 entry points) and lands
+    on the optimum of the rounded problem."""
+    torch = _torch()
+    from oracle import glm
+    import vittles_amd as va
+    from vittles_amd.optim import newton_glm
+    N, D = 6000, 40
+    X, y, w, _, _ = _problem(N, D, "logistic", seed=11)
+    obj = va.WeightedGLMObjective(X, y, prior=1.0, dtype=torch.float32)
+    res = newton_glm(obj, w)
+    theta = res[0] if isinstance(res, tuple) else res
+    theta = theta.cpu().numpy() if hasattr(theta, "cpu") else np.asarray(theta)
+    X32 = X.astype(np.float32).astype(np.float64)
+    assert relerr(theta, glm.newton_optimum("logistic", X32, y, w, prior=1.0)) < 1e-6
+    assert relerr(theta, glm.newton_optimum("logistic", X, y, w, prior=1.0)) < MODE
+
+
+def test_fp32_limits_raise_clearly():
+    torch = _torch()
+    import vittles_amd as va
+    from vittles_amd._lib import VittlesHipError
+    X, y, w, theta, _ = _problem(300, 200, "logistic", seed=2)
+    obj = va.WeightedGLMObjective(X, y, prior=1.0, dtype=torch.float32)
+    with pytest.raises(VittlesHipError) as e:
+        obj.fused(theta, w)
+    assert "fp32 mode" in str(e.value)
+    # the batched prediction and the Taylor expansion are fp64-only
+    X, y, w, theta, _ = _problem(300, 10, "logistic", seed=2)
+    obj = va.WeightedGLMObjective(X, y, prior=1.0, dtype=torch.float32)
+    sens = va.HyperparameterSensitivityLinearApproximation(obj, theta, w)
+    with pytest.raises(VittlesHipError) as e:
+        sens.predict_opt_par_from_hyper_par_batch(np.stack([w, w], axis=1))
+    assert "fp32 storage mode" in str(e.value)
+    with pytest.raises(ValueError):
+        va.WeightedGLMObjective(X, y, dtype=torch.float16)

@@ -76,6 +76,23 @@ SIGNATURES = {
     "vt_arrow_back": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "vt_glm_value": (c_int, [c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_i64, c_int,
                              c_ptr, c_ptr, c_size_t, c_ptr]),
+    # fp32 storage mode: same argument lists as the fp64 namesakes (pointers travel as integers)
+    "vt_glm_hessian_f32_workspace_bytes": (c_size_t, [c_i64, c_int]),
+    "vt_glm_hessian_f32": (c_int, [c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_ptr, c_i64, c_int,
+                                   c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_size_t, c_ptr]),
+    "vt_trsm_pack_f32_bytes": (c_size_t, [c_int]),
+    "vt_trsm_pack_f32": (c_int, [c_ptr, c_int, c_ptr, c_ptr]),
+    "vt_trsm_rows_f32": (c_int, [c_ptr, c_int, c_ptr, c_i64, c_ptr, c_dbl, c_i64, c_ptr, c_i64, c_ptr]),
+    "vt_glm_link_f32": (c_int, [c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_i64, c_int,
+                                c_ptr, c_ptr, c_ptr, c_ptr, c_size_t, c_ptr]),
+    "vt_glm_grad_f32": (c_int, [c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_ptr, c_i64, c_int,
+                                c_ptr, c_ptr, c_ptr, c_ptr, c_size_t, c_ptr]),
+    "vt_glm_hvp_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_dbl, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size_t,
+                               c_ptr]),
+    "vt_gemv_t_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size_t, c_ptr]),
+    "vt_gemv_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size_t, c_ptr]),
+    "vt_glm_value_f32": (c_int, [c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_i64, c_int,
+                                 c_ptr, c_ptr, c_size_t, c_ptr]),
 }
 
 _lib = None
@@ -101,6 +118,17 @@ def load():
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+def fn(lib, name, t):
+    """The entry point ``name`` for the storage type of the CUDA tensor ``t`` (fp32 mode: ``name_f32``)."""
+    import torch
+    if t.dtype == torch.float32:
+        return getattr(lib, name + "_f32")
+    if t.dtype != torch.float64:
+        raise VittlesHipError("%s: tensors must be float64 (or float32 in the fp32 storage mode), got %s"
+                              % (name, t.dtype))
+    return getattr(lib, name)
 
 
 def check(code, what=""):

@@ -2,7 +2,7 @@
 #include "vt_common.h"
 #include <atomic>
 
-extern "C" int vt_version(void) { return 101; }   // 101: global_terms argument of vt_vi_*
+extern "C" int vt_version(void) { return 102; }   // 101: global_terms argument of vt_vi_*; 102: the *_f32 entry points
 
 extern "C" const char* vt_error_string(int code) {
     switch (code) {

@@ -16,6 +16,7 @@
 //   `self._sens_mat @ (new_hyper - hyper0)`            vittles/sensitivity_lib.py:245-247
 #include "vt_common.h"
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -23,7 +24,8 @@ enum RowOp { OP_LINK = 0, OP_GRAD = 1, OP_HVP = 2, OP_GEMVT = 3, OP_VALUE = 4, O
              OP_TAYLOR2 = 7, OP_TAYLOR3 = 8 };
 
 struct RowArgs {
-    const double* X;
+    const void* X;         // (N, ldx) row-major, double -- or float for the *_f32 entry points (fp32 storage mode:
+                           // half the HBM bytes of these HBM-bound kernels; every sum is still carried in fp64)
     int64_t ldx;
     int64_t N;
     int D;
@@ -120,7 +122,12 @@ __device__ __forceinline__ double row_op(const RowArgs& a, int64_t n, const RowS
 
 // TEAM threads per row, each owning CPT chunks of VEC doubles: column of element e of
 // chunk k = VEC * (tt + TEAM * k) + e.   WG = max(TEAM, 256) threads.
-template <int OP, int TEAM, int CPT, int VEC, int NT>
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+template <typename XT> struct RowVec2;
+template <> struct RowVec2<double> { typedef f64x2u type; };
+template <> struct RowVec2<float> { typedef f32x2u type; };
+
+template <int OP, int TEAM, int CPT, int VEC, int NT, typename XT>
 __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
     constexpr int WG = 256;
     constexpr int TEAMS = WG / TEAM;
@@ -157,16 +164,17 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
         int64_t n = gteam + it * total_teams;
         bool valid = n < a.N;
         int64_t nc = valid ? n : a.N - 1;
-        const double* xr = a.X + nc * a.ldx;
+        const XT* xr = (const XT*)a.X + nc * a.ldx;
         double x[NE];
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             if constexpr (VEC == 2) {
-                f64x2u t = NT ? __builtin_nontemporal_load((const f64x2u*)(xr + coff[k])) : *(const f64x2u*)(xr + coff[k]);
-                x[2 * k] = t[0];
-                x[2 * k + 1] = t[1];
+                using V2 = typename RowVec2<XT>::type;
+                V2 t = NT ? __builtin_nontemporal_load((const V2*)(xr + coff[k])) : *(const V2*)(xr + coff[k]);
+                x[2 * k] = (double)t[0];
+                x[2 * k + 1] = (double)t[1];
             } else {
-                x[k] = NT ? __builtin_nontemporal_load(xr + coff[k]) : xr[coff[k]];
+                x[k] = (double)(NT ? __builtin_nontemporal_load(xr + coff[k]) : xr[coff[k]]);
             }
         }
         RowScal sc = load_scal<OP>(a, nc);
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(kWideTeam) void k_rows_wide(RowArgs a) {
     {
         bool ok = g < a.N;
         int64_t nc = ok ? g : 0;
-        r = row_rsrc(a.X + nc * a.ldx, ok ? rowbytes : 0);
+        r = row_rsrc((const double*)a.X + nc * a.ldx, ok ? rowbytes : 0);
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             if (k < P) q[k].load(r, voff + kStep * k);
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(kWideTeam) void k_rows_wide(RowArgs a) {
             int64_t n1 = n + Tn;
             bool ok = n1 < a.N;
             int64_t nc = ok ? n1 : 0;
-            r = row_rsrc(a.X + nc * a.ldx, ok ? rowbytes : 0);
+            r = row_rsrc((const double*)a.X + nc * a.ldx, ok ? rowbytes : 0);
 #pragma unroll
             for (int k = 0; k < P; ++k) q[k].load(r, voff + kStep * k);
             sn = load_scal<OP>(a, nc);
@@ -443,13 +451,13 @@ bool pick_cfg(int D, bool vec2, RowCfg& c) {
 
 int max_grid() { return num_cu() * 4; }
 
-template <int OP, int TEAM, int CPT, int VEC>
+template <int OP, int TEAM, int CPT, int VEC, typename XT>
 void launch_one(const RowArgs& a, int grid, bool nt, hipStream_t st) {
     constexpr int WG = 256;
     constexpr int TEAMS = WG / TEAM;
     size_t shmem = TEAMS > 1 ? (size_t)TEAMS * TEAM * CPT * VEC * sizeof(double) : 0;
-    if (nt) hipLaunchKernelGGL((k_rows<OP, TEAM, CPT, VEC, 1>), dim3(grid), dim3(WG), shmem, st, a);
-    else hipLaunchKernelGGL((k_rows<OP, TEAM, CPT, VEC, 0>), dim3(grid), dim3(WG), shmem, st, a);
+    if (nt) hipLaunchKernelGGL((k_rows<OP, TEAM, CPT, VEC, 1, XT>), dim3(grid), dim3(WG), shmem, st, a);
+    else hipLaunchKernelGGL((k_rows<OP, TEAM, CPT, VEC, 0, XT>), dim3(grid), dim3(WG), shmem, st, a);
 }
 
 template <int OP, int VEC, int CPT, int P>
@@ -461,17 +469,17 @@ int launch_wide(const RowArgs& a, int grid, hipStream_t st) {
     return VT_OK;
 }
 
-template <int OP, int VEC>
+template <int OP, int VEC, typename XT>
 int launch_cfg(const RowArgs& a, const RowCfg& c, int grid, bool nt, hipStream_t st) {
 #define VT_CASE(TEAM, CPT)                                   \
     if (c.team == TEAM && c.cpt == CPT) {                    \
-        launch_one<OP, TEAM, CPT, VEC>(a, grid, nt, st);     \
+        launch_one<OP, TEAM, CPT, VEC, XT>(a, grid, nt, st); \
         return VT_OK;                                        \
     }
     VT_CASE(16, 1) VT_CASE(16, 2) VT_CASE(16, 4) VT_CASE(64, 2) VT_CASE(64, 4) VT_CASE(64, 8)
     VT_CASE(256, 4) VT_CASE(256, 8)
 #undef VT_CASE
-    if (c.team == kWideTeam) {
+    if constexpr (std::is_same<XT, double>::value) if (c.team == kWideTeam) {   // wide rows: fp64 storage only
         // (chunks, prefetched chunks): full double buffering while the registers allow it
         if constexpr (VEC == 2) {
             if (c.cpt == 5) return launch_wide<OP, 2, 5, 5>(a, grid, st);
@@ -489,9 +497,9 @@ int launch_cfg(const RowArgs& a, const RowCfg& c, int grid, bool nt, hipStream_t
 }
 
 // Run one row op.  Returns the number of partial slabs written (>0) or an error (<0).
-template <int OP>
+template <int OP, typename XT = double>
 int run_rows(RowArgs a, hipStream_t st) {
-    bool vec2 = (a.D % 2 == 0) && (a.ldx % 2 == 0) && (((uintptr_t)a.X) % 16 == 0);
+    bool vec2 = (a.D % 2 == 0) && (a.ldx % 2 == 0) && (((uintptr_t)a.X) % (2 * sizeof(XT)) == 0);
     RowCfg c;
     if (!pick_cfg(a.D, vec2, c)) return VT_ERR_UNSUPPORTED;
     int64_t want = (a.N + c.teams - 1) / c.teams;
@@ -499,8 +507,8 @@ int run_rows(RowArgs a, hipStream_t st) {
     int cap = c.wg == kWideTeam ? num_cu() : max_grid();
     int grid = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
     // stream X past the caches once it is larger than the Infinity Cache can hold
-    bool nt = (double)a.N * a.D * 8.0 > 192.0e6;
-    int rc = vec2 ? launch_cfg<OP, 2>(a, c, grid, nt, st) : launch_cfg<OP, 1>(a, c, grid, nt, st);
+    bool nt = (double)a.N * a.D * (double)sizeof(XT) > 192.0e6;
+    int rc = vec2 ? launch_cfg<OP, 2, XT>(a, c, grid, nt, st) : launch_cfg<OP, 1, XT>(a, c, grid, nt, st);
     if (rc != VT_OK) return rc;
     if (hipGetLastError() != hipSuccess) return VT_ERR_HIP;
     return grid;
@@ -703,4 +711,85 @@ extern "C" int vt_glm_hvp_noalloc(const double* X, int64_t ldx, const double* d,
     }
     bool has_prior = prior != nullptr || prior_scalar != 0.0;
     return finalize(ptr, D, P, D, 0, 1.0, prior, has_prior ? v : nullptr, prior_scalar, out, st);
+}
+
+// ---- fp32 storage mode (BASELINE.json north_star: "optional fp32 mode", 1e-4): X (or any streamed matrix) is
+// float, D <= 4096; vectors, per-row outputs and every accumulation stay fp64.  Same kernels, XT = float.
+extern "C" int vt_glm_link_f32(int family, const float* X, int64_t ldx, const double* theta, const double* y,
+                               const double* w, const double* offset, double scale, int64_t N, int D,
+                               double* z_out, double* r_out, double* d_out, void* ws, size_t ws_bytes,
+                               void* stream) {
+    VT_ROWS_PROLOGUE
+    if (N == 0) return VT_OK;
+    if (!theta || !y || !w) return VT_ERR_BAD_ARG;
+    RowArgs a{X, ldx, N, D, theta, y, w, offset, nullptr, scale, family, z_out, r_out, d_out, (double*)ws};
+    int P = run_rows<OP_LINK, float>(a, st);
+    return P < 0 ? P : VT_OK;
+}
+
+extern "C" int vt_glm_grad_f32(int family, const float* X, int64_t ldx, const double* theta, const double* y,
+                               const double* w, const double* offset, double scale, const double* prior,
+                               int64_t N, int D, double* g_out, double* r_out, double* d_out, void* ws,
+                               size_t ws_bytes, void* stream) {
+    VT_ROWS_PROLOGUE
+    if (!theta || !g_out || (N > 0 && (!y || !w))) return VT_ERR_BAD_ARG;
+    int P = 0;
+    if (N > 0) {
+        RowArgs a{X, ldx, N, D, theta, y, w, offset, nullptr, scale, family, nullptr, r_out, d_out, (double*)ws};
+        P = run_rows<OP_GRAD, float>(a, st);
+        if (P < 0) return P;
+    }
+    return finalize((const double*)ws, D, P, D, 0, 1.0, prior, prior ? theta : nullptr, 0.0, g_out, st);
+}
+
+extern "C" int vt_glm_hvp_f32(const float* X, int64_t ldx, const double* d, const double* prior,
+                              double prior_scalar, const double* v, int64_t N, int D, double* out, void* ws,
+                              size_t ws_bytes, void* stream) {
+    VT_ROWS_PROLOGUE
+    if (!v || !out || (N > 0 && !d)) return VT_ERR_BAD_ARG;
+    int P = 0;
+    if (N > 0) {
+        RowArgs a{X, ldx, N, D, v, nullptr, nullptr, nullptr, d, 1.0, 0, nullptr, nullptr, nullptr, (double*)ws};
+        P = run_rows<OP_HVP, float>(a, st);
+        if (P < 0) return P;
+    }
+    bool has_prior = prior != nullptr || prior_scalar != 0.0;
+    return finalize((const double*)ws, D, P, D, 0, 1.0, prior, has_prior ? v : nullptr, prior_scalar, out, st);
+}
+
+extern "C" int vt_gemv_t_f32(const float* X, int64_t ldx, const double* u, int64_t N, int D, double* out,
+                             void* ws, size_t ws_bytes, void* stream) {
+    VT_ROWS_PROLOGUE
+    if (!out || (N > 0 && !u)) return VT_ERR_BAD_ARG;
+    int P = 0;
+    if (N > 0) {
+        RowArgs a{X, ldx, N, D, nullptr, nullptr, nullptr, nullptr, u, 1.0, 0, nullptr, nullptr, nullptr, (double*)ws};
+        P = run_rows<OP_GEMVT, float>(a, st);
+        if (P < 0) return P;
+    }
+    return finalize((const double*)ws, D, P, D, 0, 1.0, nullptr, nullptr, 0.0, out, st);
+}
+
+extern "C" int vt_gemv_f32(const float* X, int64_t ldx, const double* v, int64_t N, int D, double* out,
+                           void* ws, size_t ws_bytes, void* stream) {
+    VT_ROWS_PROLOGUE
+    if (N == 0) return VT_OK;
+    if (!v || !out) return VT_ERR_BAD_ARG;
+    RowArgs a{X, ldx, N, D, v, nullptr, nullptr, nullptr, nullptr, 1.0, 0, out, nullptr, nullptr, (double*)ws};
+    int P = run_rows<OP_GEMV, float>(a, st);
+    return P < 0 ? P : VT_OK;
+}
+
+extern "C" int vt_glm_value_f32(int family, const float* X, int64_t ldx, const double* theta, const double* y,
+                                const double* w, const double* offset, double scale, int64_t N, int D,
+                                double* value_out, void* ws, size_t ws_bytes, void* stream) {
+    VT_ROWS_PROLOGUE
+    if (!theta || !value_out || (N > 0 && (!y || !w))) return VT_ERR_BAD_ARG;
+    int P = 0;
+    if (N > 0) {
+        RowArgs a{X, ldx, N, D, theta, y, w, offset, nullptr, scale, family, nullptr, nullptr, nullptr, (double*)ws};
+        P = run_rows<OP_VALUE, float>(a, st);
+        if (P < 0) return P;
+    }
+    return finalize((const double*)ws, D, P, 1, D, scale, nullptr, nullptr, 0.0, value_out, st);
 }

@@ -13,6 +13,7 @@ class DeviceCholesky:
         self.L = L                  # (D, D) CUDA fp64, lower triangle valid
         self.D = L.shape[0]
         self._pack = pack           # MFMA TRSM operand images (lazy)
+        self._pack32 = None         # the same images in float for the fp32 storage mode (lazy)
         self._info = info           # device int32: LAPACK-style potrf info (None = known good)
 
     def raise_if_failed(self):
@@ -121,8 +122,22 @@ class DeviceCholesky:
                                         dev.stream_ptr()), "vt_trsm_pack")
         return self._pack
 
+    def pack32(self):
+        if self._pack32 is None:
+            lib = dev.require_gpu()
+            nbytes = lib.vt_trsm_pack_f32_bytes(self.D)
+            if nbytes == 0:
+                raise _lib.VittlesHipError("the fp32 mode's TRSM supports D <= 128 (got %d)" % self.D)
+            pk = self.pack()
+            self._pack32 = torch.empty(nbytes // 4, dtype=torch.float32, device=self.L.device)
+            _lib.check(lib.vt_trsm_pack_f32(pk.data_ptr(), self.D, self._pack32.data_ptr(), dev.stream_ptr()),
+                       "vt_trsm_pack_f32")
+        return self._pack32
+
     def solve_rows(self, B, rowscale=None, alpha=1.0, out=None):
-        """out[n, :] = alpha * rowscale[n] * H^{-1} B[n, :]  for a row-major (N, D) B."""
+        """out[n, :] = alpha * rowscale[n] * H^{-1} B[n, :]  for a row-major (N, D) B.
+        A float32 ``B`` (fp32 storage mode) is solved by the f32 MFMA chain into a float32 result; the factor
+        itself is always fp64."""
         lib = dev.require_gpu()
         N, D = B.shape
         if D != self.D:
@@ -130,10 +145,17 @@ class DeviceCholesky:
         if B.stride(1) != 1:
             B = B.contiguous()
         if out is None:
-            out = torch.empty((N, D), dtype=torch.float64, device=B.device)
+            out = torch.empty((N, D), dtype=B.dtype, device=B.device)
         # a single row's stride is arbitrary (torch reports 1 for a transposed (D, 1) column)
         ldb = B.stride(0) if N > 1 else D
         ldo = out.stride(0) if N > 1 else D
+        if B.dtype == torch.float32:
+            if out.dtype != torch.float32:
+                raise ValueError("out must be float32 like B")
+            _lib.check(lib.vt_trsm_rows_f32(self.pack32().data_ptr(), D, B.data_ptr(), ldb, dev.ptr(rowscale),
+                                            float(alpha), N, out.data_ptr(), ldo, dev.stream_ptr()),
+                       "vt_trsm_rows_f32")
+            return out
         _lib.check(lib.vt_trsm_rows(self.pack().data_ptr(), D, B.data_ptr(), ldb,
                                     dev.ptr(rowscale), float(alpha), N, out.data_ptr(), ldo,
                                     dev.stream_ptr()), "vt_trsm_rows")

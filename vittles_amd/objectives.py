@@ -55,15 +55,23 @@ class WeightedGLMObjective(RegisteredObjective):
     or torch; they are moved to the GPU once and stay resident.  ``process_group``:
     a torch.distributed group whose ranks each hold a contiguous ROW shard of
     (X, y, w); partial Hessians / gradients are all-reduced (RCCL), the prior is
-    added once, sensitivities stay sharded like X."""
+    added once, sensitivities stay sharded like X.
+
+    ``dtype=torch.float32`` selects the fp32 STORAGE mode (BASELINE.json north_star: optional, 1e-4
+    against the fp64 oracle, never the headline): X is kept -- and the sensitivity matrix returned -- in
+    float, half the HBM bytes; theta, y, w, r, d, H, g and the Cholesky factor stay double.  D <= 128 for the
+    Hessian / sensitivity, D <= 4096 for the row operators (gradient, HVP, value)."""
 
     def __init__(self, X, y, family="logistic", prior=None, scale=1.0, offset=None,
-                 device=None, process_group=None):
+                 device=None, process_group=None, dtype=torch.float64):
         dev.require_gpu()
         if family not in _lib.FAMILY:
             raise ValueError("family must be one of %s" % (tuple(_lib.FAMILY),))
+        if dtype not in (torch.float64, torch.float32):
+            raise ValueError("dtype must be torch.float64 or torch.float32")
         self.family = family
-        self.X = dev.to_device(X, device)
+        self.dtype = dtype
+        self.X = dev.to_device(X, device, dtype=dtype)
         if self.X.ndim != 2:
             raise ValueError("X must be (N, D)")
         if self.X.shape[0] > 0 and self.X.stride(1) != 1:
@@ -114,9 +122,12 @@ class WeightedGLMObjective(RegisteredObjective):
         key = (theta.data_ptr(), w.data_ptr(), theta._version, w._version)
         if self._cache_key == key:
             return self._cache
-        nbytes = lib.vt_glm_hessian_workspace_bytes(self.N, self.D)
+        f32 = self.dtype == torch.float32
+        nbytes = (lib.vt_glm_hessian_f32_workspace_bytes if f32 else lib.vt_glm_hessian_workspace_bytes)(
+            self.N, self.D)
         if nbytes == 0:
-            raise _lib.VittlesHipError("vt_glm_hessian does not support D = %d" % self.D)
+            raise _lib.VittlesHipError("vt_glm_hessian%s does not support D = %d"
+                                       % ("_f32 (fp32 mode: D <= 128)" if f32 else "", self.D))
         # scratch per stream: two streams driving one objective never share it
         skey = dev.stream_ptr()
         if self._ws is None:
@@ -134,7 +145,7 @@ class WeightedGLMObjective(RegisteredObjective):
         r = torch.empty(self.N, dtype=torch.float64, device=self.device)
         d = torch.empty(self.N, dtype=torch.float64, device=self.device)
         prior = self.prior if self._rank() == 0 else None
-        _lib.check(lib.vt_glm_hessian(
+        _lib.check(_lib.fn(lib, "vt_glm_hessian", self.X)(
             _lib.FAMILY[self.family], self.X.data_ptr(), dev.ld(self.X), theta.data_ptr(),
             self.y.data_ptr(), w.data_ptr(), dev.ptr(self.offset), self.scale, dev.ptr(prior),
             self.N, self.D, H.data_ptr(), self.D, g.data_ptr(), r.data_ptr(), d.data_ptr(),
@@ -149,6 +160,12 @@ class WeightedGLMObjective(RegisteredObjective):
         return out
 
     def grad(self, opt, hyper):
+        if self.dtype == torch.float32:
+            # fp32 mode: the fused kernel's gradient is summed in f32 per wave (~1e-6 of sum |terms|), too coarse
+            # for an optimiser's stopping test; the row kernel carries the sum in fp64 (one more pass over X)
+            from . import rows
+            g, _, _ = rows.glm_grad(self, opt, hyper, prior=self.prior if self._rank() == 0 else None)
+            return self._all_reduce(g)
         return self.fused(opt, hyper)["g"]
 
     def hessian(self, opt, hyper):

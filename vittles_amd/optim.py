@@ -51,6 +51,8 @@ def newton_glm(objective, hyper_par, opt_par_init=None, max_iter=50, grad_tol=1e
     for it in range(1, max_iter + 1):
         out = objective.fused(theta, w)                     # K0 + K1 + K3 (+ all-reduce)
         g, H = out["g"], out["H"]
+        if objective.dtype == torch.float32:
+            g = objective.grad(theta, w)                    # fp64-summed gradient of the float data
         (gnorm,) = agree(rows.norm(g))
         if gnorm <= grad_tol:
             converged = True
@@ -75,8 +77,7 @@ def newton_glm(objective, hyper_par, opt_par_init=None, max_iter=50, grad_tol=1e
         snorm = t * step_norm
         theta, value = cand, cand_value
         if snorm <= step_tol * max(1.0, theta_norm):
-            out = objective.fused(theta, w)
-            (gnorm,) = agree(rows.norm(out["g"]))
+            (gnorm,) = agree(rows.norm(objective.grad(theta, w)))
             converged = gnorm <= max(grad_tol, 1e-6)
             break
     info = dict(iterations=it, grad_norm=gnorm, value=value, converged=converged, halvings=halvings_total)

@@ -42,6 +42,13 @@ def _rowmajor(A):
     return A if (A.stride(1) == 1 or A.shape[0] == 0) else A.contiguous()
 
 
+def _fp64_only(A, what):
+    if A.dtype != torch.float64:
+        raise _lib.VittlesHipError(
+            "%s is not part of the fp32 storage mode (it covers the Hessian, the sensitivity solve, gradient, HVP, "
+            "value, A v and A^T u): build the objective with dtype=torch.float64" % what)
+
+
 def gemv_t(A, u):
     """out (D,) = A^T u for a row-major (N, D) CUDA tensor A (K9)."""
     lib = dev.require_gpu()
@@ -50,8 +57,8 @@ def gemv_t(A, u):
     u = u.contiguous()
     out = torch.empty(D, dtype=torch.float64, device=A.device)
     ws = _workspace(D, A.device)
-    _lib.check(lib.vt_gemv_t(A.data_ptr(), dev.ld(A), u.data_ptr(), N, D, out.data_ptr(),
-                             ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_gemv_t")
+    _lib.check(_lib.fn(lib, "vt_gemv_t", A)(A.data_ptr(), dev.ld(A), u.data_ptr(), N, D, out.data_ptr(),
+                                            ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_gemv_t")
     return out
 
 
@@ -63,14 +70,15 @@ def gemv(A, v):
     v = v.contiguous()
     out = torch.empty(N, dtype=torch.float64, device=A.device)
     ws = _workspace(D, A.device)
-    _lib.check(lib.vt_gemv(A.data_ptr(), dev.ld(A), v.data_ptr(), N, D, out.data_ptr(),
-                           ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_gemv")
+    _lib.check(_lib.fn(lib, "vt_gemv", A)(A.data_ptr(), dev.ld(A), v.data_ptr(), N, D, out.data_ptr(),
+                                          ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_gemv")
     return out
 
 
 def gemv_t2(A, u1, u2):
     """out (D,) = A^T (u1 .* u2) for a row-major (N, D) CUDA tensor A."""
     lib = dev.require_gpu()
+    _fp64_only(A, "gemv_t2")
     A = _rowmajor(A)
     N, D = A.shape
     out = torch.empty(D, dtype=torch.float64, device=A.device)
@@ -84,6 +92,7 @@ def glm_taylor2_rhs(obj, z, w, dw, u):
     """Second-order data-weight right-hand side of a WeightedGLMObjective (one pass over X):
     scale * sum_n [w_n ell'''(z_n) (x_n.u)^2 + 2 dw_n ell''(z_n) (x_n.u)] x_n."""
     lib = dev.require_gpu()
+    _fp64_only(obj.X, "the Taylor expansion")
     out = torch.empty(obj.D, dtype=torch.float64, device=obj.device)
     ws = _workspace(obj.D, obj.device)
     _lib.check(lib.vt_glm_taylor2_rhs(_lib.FAMILY[obj.family], obj.X.data_ptr(), dev.ld(obj.X), z.data_ptr(),
@@ -97,6 +106,7 @@ def glm_taylor3_rhs(obj, z, w, dw, d1, d2=None, zeta2=None):
     """Third-order data-weight right-hand side of a WeightedGLMObjective: one pass for zeta2 = X d2
     (unless ``zeta2`` is given), one fused pass for the sum (see include/vittles_hip.h)."""
     lib = dev.require_gpu()
+    _fp64_only(obj.X, "the Taylor expansion")
     if zeta2 is None:
         zeta2 = gemv(obj.X, d2)
     out = torch.empty(obj.D, dtype=torch.float64, device=obj.device)
@@ -115,6 +125,8 @@ def gemm_tn(A, B, rowscale=None, alpha=1.0, bias=None, out=None):
     """out (Da, Db) = alpha * A^T diag(rowscale) B + bias[None, :] for row-major CUDA tensors
     A (N, Da), B (N, Db): K9 for many weight vectors at once (fp64 MFMA, split over N)."""
     lib = dev.require_gpu()
+    _fp64_only(A, "gemm_tn")
+    _fp64_only(B, "gemm_tn (batched predictions / LR covariances)")
     A, B = _rowmajor(A), _rowmajor(B)
     N, Da = A.shape
     if B.shape[0] != N:
@@ -147,7 +159,7 @@ def glm_link(obj, theta, w, want_z=False):
     r = torch.empty(obj.N, dtype=torch.float64, device=obj.device)
     d = torch.empty(obj.N, dtype=torch.float64, device=obj.device)
     ws = _workspace(obj.D, obj.device)
-    _lib.check(lib.vt_glm_link(_lib.FAMILY[obj.family], obj.X.data_ptr(), dev.ld(obj.X), theta.data_ptr(),
+    _lib.check(_lib.fn(lib, "vt_glm_link", obj.X)(_lib.FAMILY[obj.family], obj.X.data_ptr(), dev.ld(obj.X), theta.data_ptr(),
                                obj.y.data_ptr(), w.data_ptr(), dev.ptr(obj.offset), obj.scale, obj.N, obj.D,
                                dev.ptr(z), r.data_ptr(), d.data_ptr(), ws.data_ptr(), ws.numel() * 8,
                                dev.stream_ptr()), "vt_glm_link")
@@ -163,7 +175,7 @@ def glm_grad(obj, theta, w, prior=None):
     r = torch.empty(obj.N, dtype=torch.float64, device=obj.device)
     d = torch.empty(obj.N, dtype=torch.float64, device=obj.device)
     ws = _workspace(obj.D, obj.device)
-    _lib.check(lib.vt_glm_grad(_lib.FAMILY[obj.family], obj.X.data_ptr(), dev.ld(obj.X), theta.data_ptr(),
+    _lib.check(_lib.fn(lib, "vt_glm_grad", obj.X)(_lib.FAMILY[obj.family], obj.X.data_ptr(), dev.ld(obj.X), theta.data_ptr(),
                                obj.y.data_ptr(), w.data_ptr(), dev.ptr(obj.offset), obj.scale, dev.ptr(prior),
                                obj.N, obj.D, g.data_ptr(), r.data_ptr(), d.data_ptr(), ws.data_ptr(),
                                ws.numel() * 8, dev.stream_ptr()), "vt_glm_grad")
@@ -177,7 +189,7 @@ def glm_hvp(X, d, v, prior=None, prior_scalar=0.0, out=None):
     if out is None:
         out = torch.empty(D, dtype=torch.float64, device=X.device)
     ws = _workspace(D, X.device)
-    _lib.check(lib.vt_glm_hvp(X.data_ptr(), dev.ld(X), d.data_ptr(), dev.ptr(prior), float(prior_scalar),
+    _lib.check(_lib.fn(lib, "vt_glm_hvp", X)(X.data_ptr(), dev.ld(X), d.data_ptr(), dev.ptr(prior), float(prior_scalar),
                               v.data_ptr(), N, D, out.data_ptr(), ws.data_ptr(), ws.numel() * 8,
                               dev.stream_ptr()), "vt_glm_hvp")
     return out
@@ -190,7 +202,7 @@ def glm_value(obj, theta, w):
     w = dev.to_device(w, obj.device).contiguous()
     val = torch.empty(1, dtype=torch.float64, device=obj.device)
     ws = _workspace(obj.D, obj.device)
-    _lib.check(lib.vt_glm_value(_lib.FAMILY[obj.family], obj.X.data_ptr(), dev.ld(obj.X), theta.data_ptr(),
+    _lib.check(_lib.fn(lib, "vt_glm_value", obj.X)(_lib.FAMILY[obj.family], obj.X.data_ptr(), dev.ld(obj.X), theta.data_ptr(),
                                 obj.y.data_ptr(), w.data_ptr(), dev.ptr(obj.offset), obj.scale, obj.N, obj.D,
                                 val.data_ptr(), ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_glm_value")
     obj._all_reduce(val)
