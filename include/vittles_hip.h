@@ -233,9 +233,12 @@ int    vt_glm_value(int family, const double* X_dev, int64_t ldx, const double* 
 
 /* ---- fp32 STORAGE mode (BASELINE.json north_star: "optional fp32 mode", 1e-4 against the fp64 oracle) ------
  * The two N x D arrays that set the HBM traffic -- X and the sensitivity matrix S -- are float; theta, y, w,
- * offset, the per-row factors r and d, H, g, the Cholesky factor and every D-vector stay double.  Row sums are
- * carried in fp64; the two MFMA kernels multiply in f32 (v_mfma_f32_16x16x4_f32) and fold their f32 accumulators
- * into fp64 every <= 4096 rows.  D <= VT_SMALL_D_MAX for the Hessian / TRSM, D <= 4096 for the row operators;
+ * offset, the per-row factors r and d, H, g, the Cholesky factor and every D-vector stay double.  The row
+ * operators carry every sum in fp64 (they agree with fp64 arithmetic on the rounded X to ~1e-12); the two MFMA
+ * kernels multiply in f32 (v_mfma_f32_16x16x4_f32), vt_glm_hessian_f32 also takes its row dot x_n . theta in f32
+ * (its r, d, g are f32-accurate, ~1e-6: use vt_glm_grad_f32 / vt_glm_link_f32 where fp64 sums matter, e.g. an
+ * optimiser's stopping test) and folds its f32 accumulators into fp64 every <= 4096 rows per wave.
+ * D <= VT_SMALL_D_MAX for the Hessian / TRSM, D <= 4096 for the row operators;
  * anything larger returns VT_ERR_UNSUPPORTED (use the fp64 entry points).  Each entry point replaces the same
  * reference lines as its fp64 namesake above and takes the same arguments, with float where noted. */
 size_t vt_glm_hessian_f32_workspace_bytes(int64_t N, int D);

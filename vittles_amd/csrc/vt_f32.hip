@@ -1,7 +1,7 @@
 // fp32 storage mode of the sensitivity path (BASELINE.json north_star: "optional fp32 mode", tolerance 1e-4
 // against the fp64 oracle).  X -- and the sensitivity matrix S, the two N x D arrays that set the HBM traffic --
 // are float; theta, y, w, the per-row factors r and d, H, g and the Cholesky factor stay double.
-//   vt_glm_hessian_f32 : H = X^T diag(d) X by v_mfma_f32_16x16x4_f32, link and row dot in fp64
+//   vt_glm_hessian_f32 : H = X^T diag(d) X by v_mfma_f32_16x16x4_f32, row dot in f32, link in fp64
 //   vt_trsm_pack_f32   : the fp64 TRSM operand pack (vt_potrf_pack) rounded to float, re-laid for the f32 MFMA
 //   vt_trsm_rows_f32   : S = alpha diag(s) B (L L^T)^{-1} as an MFMA chain in f32
 // The fp64 kernels replace the same reference lines (vittles/sensitivity_lib.py:354, 226); this file is the
@@ -11,6 +11,11 @@
 // kChunkSteps k-steps (4096 rows) into its f32 accumulators before they are folded into an fp64 slab in LDS:
 // the rounding error of a sum stays <= ~kChunkSteps * 2^-24 relative, whatever N is.
 #include "vt_common.h"
+#include <type_traits>
+#include <utility>
+#ifndef VT_ABL32
+#define VT_ABL32 0   // dev-only compile-time ablation mask (tools/build_dev32.sh): 1 no MFMA, 2 no link, 4 no loads in the loop
+#endif
 
 namespace {
 
@@ -43,26 +48,24 @@ struct Hess32Args {
 
 constexpr int kChunkSteps = 1024;   // k-steps a wave accumulates in f32 before folding into fp64 (multiple of 4)
 
+// A GROUP is 4 consecutive k-steps of a wave = 16 rows.  x: lane (q, c) holds X[row q of step s][16 b + c];
+// y, w, off: the per-row scalars of row (step c & 3, q) -- the row this lane LINKS (below).
 template <int NB>
-struct Step32 {
-    float x[NB];
+struct Grp32 {
+    float x[4][NB];
     double y, w, off;
 };
 
-// Unconditional loads with clamped indices (see vt_hessian.hip): rows past N re-read row N-1 and get d_n = 0,
-// columns past D re-read column D-1 and land in padding that is never stored.
-template <int NB, bool HAS_OFF>
-__device__ __forceinline__ void load_step32(const Hess32Args& a, int64_t step, int q, int c, Step32<NB>& d) {
-    int64_t n = step * 4 + q;
-    n = n < a.N ? n : a.N - 1;
-    const float* xr = a.X + n * a.ldx;
-    const int clast = min(16 * (NB - 1) + c, a.D - 1);
-#pragma unroll
-    for (int b = 0; b < NB - 1; ++b) d.x[b] = xr[16 * b + c];
-    d.x[NB - 1] = xr[clast];
-    d.y = a.y[n];
-    d.w = a.w[n];
-    d.off = HAS_OFF ? a.offset[n] : 0.0;
+// v + (v rotated right by N lanes inside each row of 16 lanes): one v_add_f32 with a DPP operand
+template <int N>
+__device__ __forceinline__ float ror16_add_f32(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, true));
+}
+
+// v of lane S of each row of 16 lanes, in every lane of that row (DPP row_newbcast: one VALU move)
+template <int S>
+__device__ __forceinline__ float bcast16(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + S, 0xf, 0xf, true));
 }
 
 // Every wave owns the WHOLE block triangle in f32 accumulators (NBT * 4 <= 144 registers) and streams its own
@@ -70,22 +73,36 @@ __device__ __forceinline__ void load_step32(const Hess32Args& a, int64_t step, i
 // k_glm_hess_small without the split of the triangle over two waves, which fp64 needs and f32 does not.
 // WAVES = 8 (two per SIMD, 256 registers each) up to NB = 5; 4 (one per SIMD, accumulators in the AGPR half of
 // its 512 registers) above: an f32 MFMA wave with independent accumulators reaches the issue rate alone.
+//
+// VALU instructions do NOT overlap v_mfma_f32_16x16x4_f32 on gfx950 -- neither from the same wave nor from another
+// wave of the SIMD; the times add (tools/micro/mfma_f32_valu_overlap.hip: "both" = MFMA + VALU in every
+// arrangement; the instruction runs at the f32 VECTOR rate) -- so the kernel is MFMA cycles (32 each) + VALU
+// cycles (3.5 per f32 op, 5.5 .. 8 per fp64 op), and the VALU work per k-step is cut to the bone:
+//   * the row dot x_n . theta is taken in f32 against theta rounded to float (7 FMAs + 4 DPP adds per k-step; in
+//     fp64 it was 7 conversions + 7 FMAs + 12 DPP instructions at twice the cycles each).  z, and with it r and d,
+//     are therefore f32-accurate (~1e-6): inside the mode's 1e-4, and the optimiser's gradient comes from
+//     vt_glm_grad_f32, which sums in fp64;
+//   * the link (exp, reciprocal, ... ~60 fp64 instructions) is evaluated ONCE per row instead of once per lane
+//     of the row's 16-lane group: the row dots of a group's 4 k-steps leave z of row (s, q) in all 16 lanes of
+//     lane row q; lane (q, c) keeps the one of step c & 3, links it, and the MFMAs of step s fetch d_n and
+//     w_n r_n from lane (q, s) by DPP row broadcast.
 template <int NB, int FAM, bool HAS_OFF, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_glm_hess_f32(Hess32Args a) {
     constexpr int NT = WAVES * 64;
     constexpr int NBT = NB * (NB + 1) / 2;
     constexpr int L = NBT * 256 + NB * 16;
-    extern __shared__ double lds[];   // fp64 slab [NBT*256] | gradient [NB*16] | theta [NB*16]
+    extern __shared__ double lds[];   // fp64 slab [NBT*256] | gradient [NB*16] | theta as float [NB*16]
     double* slab = lds;
     double* gsum = lds + NBT * 256;
-    double* th = lds + L;
+    float* th = (float*)(lds + L);
     for (int t = threadIdx.x; t < L; t += NT) lds[t] = 0.0;
-    for (int t = threadIdx.x; t < NB * 16; t += NT) th[t] = t < a.D ? a.theta[t] : 0.0;
+    for (int t = threadIdx.x; t < NB * 16; t += NT) th[t] = t < a.D ? (float)a.theta[t] : 0.f;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int q = lane >> 4, c = lane & 15;
+    const int q = lane >> 4, c = lane & 15, cs = lane & 3;
+    const int clast = min(16 * (NB - 1) + c, a.D - 1);
     const int64_t nsteps = (a.N + 3) >> 2;
     const int64_t W = (int64_t)gridDim.x * WAVES;
     const int64_t gw = (int64_t)blockIdx.x * WAVES + wave;
@@ -103,71 +120,97 @@ __global__ __launch_bounds__(WAVES * 64) void k_glm_hess_f32(Hess32Args a) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) gacc[b] = 0.f;
 
-        struct Link { float dw, gwt; };
-        // the wave's t-th k-step is global k-step gw + W t
-        auto link = [&](int64_t t, const Step32<NB>& sd) -> Link {
-            const int64_t n = (gw + W * t) * 4 + q;
-            const bool rowok = t < t1 && n < a.N;
-            double p = 0.0;
+        // The wave's t-th k-step is global k-step gw + W t.  Unconditional loads with clamped indices (see
+        // vt_hessian.hip): rows past N re-read row N-1 and get d_n = 0, columns past D re-read column D-1 and land
+        // in padding that is never stored.
+        auto load_group = [&](int64_t tg, Grp32<NB>& d) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) p = fma((double)sd.x[b], th[16 * b + c], p);
-            double z = vt_sum16_dpp(p);
-            if (HAS_OFF) z += sd.off;
+            for (int s = 0; s < 4; ++s) {
+                int64_t n = (gw + W * (tg + s)) * 4 + q;
+                n = n < a.N ? n : a.N - 1;
+                const float* xr = a.X + n * a.ldx;
+#pragma unroll
+                for (int b = 0; b < NB - 1; ++b) d.x[s][b] = xr[16 * b + c];
+                d.x[s][NB - 1] = xr[clast];
+            }
+            int64_t nl = (gw + W * (tg + cs)) * 4 + q;
+            nl = nl < a.N ? nl : a.N - 1;
+            d.y = a.y[nl];
+            d.w = a.w[nl];
+            d.off = HAS_OFF ? a.offset[nl] : 0.0;
+        };
+        struct Link { float dw, gwt; };   // of row (step c & 3, q)
+        auto link_group = [&](int64_t tg, const Grp32<NB>& d) -> Link {
+            float thv[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) thv[b] = th[16 * b + c];
+            float z[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float p = 0.f;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) p = fmaf(d.x[s][b], thv[b], p);
+                p = ror16_add_f32<8>(p);
+                p = ror16_add_f32<4>(p);
+                p = ror16_add_f32<2>(p);
+                z[s] = ror16_add_f32<1>(p);
+            }
+            double zz = (double)(cs == 0 ? z[0] : (cs == 1 ? z[1] : (cs == 2 ? z[2] : z[3])));
+            const int64_t ts = tg + cs;
+            const int64_t n = (gw + W * ts) * 4 + q;
+            const bool rowok = ts < t1 && n < a.N;
+            if (HAS_OFF) zz += d.off;
             double l1, l2;
-            vt_link(FAM, z, sd.y, l1, l2);
+            if (VT_ABL32 & 2) { l1 = zz; l2 = 1.0; } else
+            vt_link(FAM, zz, d.y, l1, l2);
             const double rr = a.scale * l1;
-            const double dw = rowok ? a.scale * sd.w * l2 : 0.0;
-            const bool st = rowok && c == 0;
+            const double dw = rowok ? a.scale * d.w * l2 : 0.0;
+            // branch-free per-row outputs: lanes with nothing to store write to a sink
+            const bool st = rowok && c < 4;
             double* rp = (st && a.r_out) ? a.r_out + n : a.sink + threadIdx.x;
             double* dp = (st && a.d_out) ? a.d_out + n : a.sink + 512 + threadIdx.x;
             *rp = rr;
             *dp = dw;
             Link lk;
             lk.dw = (float)dw;
-            lk.gwt = rowok ? (float)(sd.w * rr) : 0.f;
+            lk.gwt = rowok ? (float)(d.w * rr) : 0.f;
             return lk;
         };
-        auto mfmas = [&](const Step32<NB>& sd, const Link& lk) {
+        auto mfma_step = [&](const float (&x)[NB], float dws, float gws) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) gacc[b] = fmaf(lk.gwt, sd.x[b], gacc[b]);
+            for (int b = 0; b < NB; ++b) gacc[b] = fmaf(gws, x[b], gacc[b]);
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const float bj = lk.dw * sd.x[j];
+                const float bj = dws * x[j];
 #pragma unroll
-                for (int i = j; i < NB; ++i) acc[vt_tri(i, j)] = mfma_f32(sd.x[i], bj, acc[vt_tri(i, j)]);
+                for (int i = j; i < NB; ++i) {
+                    if (VT_ABL32 & 1) acc[vt_tri(i, j)][0] += x[i] * bj; else
+                    acc[vt_tri(i, j)] = mfma_f32(x[i], bj, acc[vt_tri(i, j)]);
+                }
             }
         };
-        auto step_of = [&](int64_t t) { return gw + W * t; };
+        auto mfma_group = [&](const Grp32<NB>& d, const Link& lk) {
+            mfma_step(d.x[0], bcast16<0>(lk.dw), bcast16<0>(lk.gwt));
+            mfma_step(d.x[1], bcast16<1>(lk.dw), bcast16<1>(lk.gwt));
+            mfma_step(d.x[2], bcast16<2>(lk.dw), bcast16<2>(lk.gwt));
+            mfma_step(d.x[3], bcast16<3>(lk.dw), bcast16<3>(lk.gwt));
+        };
 
-        // R-deep register ring, two k-steps per scheduling region (as k_glm_hess_small): region h multiplies
-        // steps (h, h+1), links steps (h+2, h+3) and refills the two buffers it has just consumed with steps
-        // (h+R, h+R+1) -- which are linked R/2 - 1 regions later.  Two waves per SIMD cover each other's HBM
-        // latency with R = 4; a wave that has its SIMD to itself needs the loads 3 regions (~2 us) ahead: R = 8.
+        // Ring of G groups, one group per region: region h multiplies group h, links group h+1 and refills the
+        // buffers it has just consumed with group h+G, which is linked G-1 regions later.  Two waves per SIMD
+        // cover each other's HBM latency with G = 2; a wave that has its SIMD to itself gets G = 3.
         // k-steps past t1 that the ring touches are linked as invalid (d = 0) and contribute nothing.
-        constexpr int R = WAVES == 8 ? 4 : 8;
-        auto interleave = [&]() {
+        constexpr int G = WAVES == 8 ? 2 : 3;
+        Grp32<NB> g[G];
 #pragma unroll
-            for (int i = 0; i < 2 * NBT; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
-            }
-        };
-        Step32<NB> x[R];
-        Link lk[R];
+        for (int i = 0; i < G; ++i) load_group(t0 + 4 * i, g[i]);
+        Link cur = link_group(t0, g[0]);
+        for (int64_t t = t0; t < t1; t += 4 * G) {
 #pragma unroll
-        for (int i = 0; i < R; ++i) load_step32<NB, HAS_OFF>(a, step_of(t0 + i), q, c, x[i]);
-        lk[0] = link(t0, x[0]);
-        lk[1] = link(t0 + 1, x[1]);
-        for (int64_t t = t0; t < t1; t += R) {
-#pragma unroll
-            for (int h = 0; h < R; h += 2) {
-                mfmas(x[h], lk[h]);
-                mfmas(x[h + 1], lk[h + 1]);
-                lk[(h + 2) % R] = link(t + h + 2, x[(h + 2) % R]);
-                lk[(h + 3) % R] = link(t + h + 3, x[(h + 3) % R]);
-                interleave();
-                load_step32<NB, HAS_OFF>(a, step_of(t + h + R), q, c, x[h]);
-                load_step32<NB, HAS_OFF>(a, step_of(t + h + R + 1), q, c, x[h + 1]);
+            for (int h = 0; h < G; ++h) {
+                mfma_group(g[h], cur);
+                cur = link_group(t + 4 * (h + 1), g[(h + 1) % G]);
+                if (!(VT_ABL32 & 4)) load_group(t + 4 * (h + G), g[h]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -493,6 +536,9 @@ extern "C" int vt_glm_hessian_f32(int family, const float* X, int64_t ldx, const
         Hess32Args a{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, sink};
         int rc = VT_ERR_UNSUPPORTED;
         switch (NB) {
+#ifdef VT_F32_DEV_NB   // dev builds (tools/build_dev32.sh): one block count only, to keep the compile short
+            case VT_F32_DEV_NB: rc = launch_hess32<VT_F32_DEV_NB>(a, grid, st); break;
+#else
             case 1: rc = launch_hess32<1>(a, grid, st); break;
             case 2: rc = launch_hess32<2>(a, grid, st); break;
             case 3: rc = launch_hess32<3>(a, grid, st); break;
@@ -501,6 +547,7 @@ extern "C" int vt_glm_hessian_f32(int family, const float* X, int64_t ldx, const
             case 6: rc = launch_hess32<6>(a, grid, st); break;
             case 7: rc = launch_hess32<7>(a, grid, st); break;
             case 8: rc = launch_hess32<8>(a, grid, st); break;
+#endif
         }
         if (rc != VT_OK) return rc;
     }
