@@ -15,6 +15,10 @@
 #include "vt_common.h"
 #include <cstdlib>
 
+#ifndef VT_LABL
+#define VT_LABL 0   // dev-only compile-time ablation mask of k_gemm_nt_lds: 1 no DMA after the prologue, 2 no MFMA
+#endif
+
 namespace {
 
 constexpr int kT = 128;            // tile / panel width
@@ -136,71 +140,92 @@ __device__ __forceinline__ void lg_wait4_barrier() {
 
 // C = beta C + alpha A B^T.  LDS panel layout [k/2][row][2]: one DMA instruction moves (64 rows) x
 // (2 k) and MFMA operand reads (lane = row, k) are bank-conflict free.
-template <bool LOWER, int STAGES>
-__global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
+// TM x 128 output tile per workgroup, 8 waves (2 per SIMD):
+//   TM = 128: 2 x 4 waves of 64 x 32.  32 KB per stage; with 2 stages two workgroups share a CU.
+//   TM = 256: 4 x 2 waves of 64 x 64 (128 accumulator registers).  48 KB per stage, 3 stages, one workgroup per
+//             CU.  Per stage the DMA brings (TM + 128) x 16 doubles for 2 TM 128 16 flops: 16 flop/B at TM = 128
+//             (8 B/cycle/CU at the MFMA peak, two thirds of what LDS-DMA delivers, MI355X_MICROARCH.md price
+//             list) and 21 flop/B at TM = 256 -- and 8 operand reads feed 16 MFMAs instead of 6 feeding 8.
+template <bool LOWER, int STAGES, int TM, int WAVES = 8>
+__global__ __launch_bounds__(WAVES * 64) void k_gemm_nt_lds(GemmArgs a) {
     if (LOWER && blockIdx.y > blockIdx.x) return;
-    extern __shared__ double lds[];            // [STAGES][A: 8 planes x 128 rows x 2 | B: same]
-    constexpr int PANEL = (kKC / 2) * kT * 2;  // 2048 doubles
+    extern __shared__ double lds[];            // [STAGES][A: 8 planes x TM rows x 2 | B: 8 planes x 128 rows x 2]
+    constexpr int WM = TM / 64, WN = WAVES / WM;   // wave grid
+    constexpr int NJ = kT / WN / 16;           // 16-column blocks per wave
+    constexpr int PA = (kKC / 2) * TM * 2, PB = (kKC / 2) * kT * 2, STAGE = PA + PB;
+    constexpr int NDMA = (kKC / 2) * (TM / 64 + kT / 64);   // DMA instructions per stage
+    constexpr int PER_WAVE = NDMA / WAVES;
+    static_assert(NDMA % WAVES == 0 && (PER_WAVE == 3 || PER_WAVE == 4 || PER_WAVE == 6), "DMA split");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;   // 2 x 4 waves of 64 x 32
+    const int wm = wave / WN, wn = wave % WN;
     const int q = lane >> 4, c = lane & 15;
-    const int64_t m0 = (int64_t)blockIdx.x * kT;
+    const int64_t m0 = (int64_t)blockIdx.x * TM;
     const int n0 = blockIdx.y * kT;
-    const int mrem = (int)min((int64_t)kT, a.M - m0), nrem = min(kT, a.N - n0);
+    const int mrem = (int)min((int64_t)TM, a.M - m0), nrem = min(kT, a.N - n0);
     const int nk = (a.K + kKC - 1) / kKC;
 
-    // this wave's 4 DMA instructions of a stage: ids wave*4 .. wave*4+3 of 32 (16 for A, 16 for B)
+    // this wave's DMA instructions of a stage: ids wave*PER_WAVE .. of NDMA (A first, then B)
     auto issue = [&](int t, int buf) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int id = wave * 4 + e;
-            const bool isb = id >= 16;
-            const int kp = (id & 15) >> 1, half = id & 1;
+        for (int e = 0; e < PER_WAVE; ++e) {
+            const int id = wave * PER_WAVE + e;
+            constexpr int NA = (kKC / 2) * (TM / 64);
+            const bool isb = id >= NA;
+            const int idl = isb ? id - NA : id;
+            const int parts = isb ? kT / 64 : TM / 64;
+            const int kp = idl / parts, part = idl % parts;
             const int k0 = t * kKC + 2 * kp;
             const int rem = isb ? nrem : mrem;
             const int64_t ld = isb ? a.ldb : a.lda;
             const double* base = (isb ? a.B + (int64_t)n0 * a.ldb : a.A + m0 * a.lda) + k0;
             // rows past the tile and k past K read 0
             const unsigned bytes = (t < nk && k0 < a.K) ? (unsigned)(((int64_t)(rem - 1) * ld + 2) * 8) : 0u;
-            double* dst = lds + buf * (2 * PANEL) + (isb ? PANEL : 0) + kp * (kT * 2) + half * 128;
+            double* dst = lds + buf * STAGE + (isb ? PA + kp * (kT * 2) : kp * (TM * 2)) + part * 128;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(lg_rsrc(base, bytes), (vt_ldsptr)dst, 16,
-                                                     (unsigned)((64 * half + lane) * ld) * 8u, 0, 0, 0);
+                                                     (unsigned)((64 * part + lane) * ld) * 8u, 0, 0, 0);
         }
     };
 
-    f64x4 acc[4][2];
+    f64x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
     issue(0, 0);
     if constexpr (STAGES == 3) issue(1, 1);
     int buf = 0;
     for (int t = 0; t < nk; ++t) {
         if constexpr (STAGES == 3) {
-            lg_wait4_barrier();
+            // the stage about to be used has landed (only the newest PER_WAVE DMA instructions of this wave may
+            // still be in flight), then everybody's part of it
+            if constexpr (PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if constexpr (PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const int b2 = buf == 0 ? 2 : buf - 1;     // (buf + 2) % 3
-            issue(t + 2, b2);
+            if (!(VT_LABL & 1)) issue(t + 2, b2);
         } else {
             // two stages (64 KB): two workgroups per CU cover each other's waits
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            issue(t + 1, buf ^ 1);
+            if (!(VT_LABL & 1)) issue(t + 1, buf ^ 1);
         }
-        const double* pa = lds + buf * (2 * PANEL) + (q >> 1) * (kT * 2) + (64 * wm + c) * 2 + (q & 1);
-        const double* pb = lds + buf * (2 * PANEL) + PANEL + (q >> 1) * (kT * 2) + (32 * wn + c) * 2 + (q & 1);
+        const double* pa = lds + buf * STAGE + (q >> 1) * (TM * 2) + (64 * wm + c) * 2 + (q & 1);
+        const double* pb = lds + buf * STAGE + PA + (q >> 1) * (kT * 2) + (16 * NJ * wn + c) * 2 + (q & 1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            double af[4], bf[2];
+            double af[4], bf[NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = pa[2 * s * (kT * 2) + 32 * i];
+            for (int i = 0; i < 4; ++i) af[i] = pa[2 * s * (TM * 2) + 32 * i];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = pb[2 * s * (kT * 2) + 32 * j];
+            for (int j = 0; j < NJ; ++j) bf[j] = pb[2 * s * (kT * 2) + 32 * j];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < NJ; ++j) {
+                    if (VT_LABL & 2) acc[i][j][0] += af[i] * bf[j]; else
+                    acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+                }
         }
         if constexpr (STAGES == 3) buf = buf == 2 ? 0 : buf + 1;
         else buf ^= 1;
@@ -209,8 +234,8 @@ __global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + 32 * wn + 16 * j + c;
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + 16 * NJ * wn + 16 * j + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t m = m0 + 64 * wm + 16 * i + q + 4 * r;
@@ -237,6 +262,22 @@ static int large_stages() {
     return st == 3 ? 3 : 2;
 }
 
+#ifndef VT_TALL_WAVES
+#define VT_TALL_WAVES 16
+#endif
+constexpr int kTallWaves = VT_TALL_WAVES;   // waves of a 256 x 128 tile: 16 (4 x 4 of 64 x 32) or 8 (4 x 2 of 64 x 64)
+
+// 256 x 128 tiles for the tall products are OFF by default: measured at N = 1.25e6, D = 1000 (whole blocked TRSM,
+// tools/time_trsm_large.py) 53.6 ms with 128-row tiles (two workgroups per CU), 66.0 ms with 8 waves of 64 x 64
+// and 56.4 ms with 16 waves of 64 x 32 on 256-row tiles: one workgroup per CU has nobody to fill the MFMA pipe
+// while all its waves re-read their operands after the stage barrier (without any DMA the three read 45.7 /
+// 58.0 / 54.4 ms), which costs more than the 25 % of LDS-DMA traffic the taller tile saves.
+// VT_LARGE_TM256=1 turns them on for A/B runs.
+static bool large_tall_tiles() {
+    static const bool v = getenv("VT_LARGE_TM256") != nullptr;
+    return v;
+}
+
 bool lds_path_ok(const double* A, int64_t lda, const double* B, int64_t ldb, int K) {
     return K % 2 == 0 && lda % 2 == 0 && ldb % 2 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
            !large_no_lds();
@@ -250,20 +291,29 @@ int gemm_nt(double* C, int64_t ldc, int64_t M, int N, const double* A, int64_t l
     dim3 grid((unsigned)((M + kT - 1) / kT), (unsigned)((N + kT - 1) / kT));
     if (lds_path_ok(A, lda, B, ldb, K)) {
         const int stages = large_stages();
-        const size_t shmem = (size_t)stages * 2 * (kKC / 2) * kT * 2 * sizeof(double);   // 96 / 64 KB
-        static VtLdsAttr attr[4];
-        const int mx = 3 * 2 * (kKC / 2) * kT * 2 * (int)sizeof(double);
-        if (vt_allow_big_lds((const void*)k_gemm_nt_lds<false, 3>, attr[0], mx) != VT_OK ||
-            vt_allow_big_lds((const void*)k_gemm_nt_lds<true, 3>, attr[1], mx) != VT_OK ||
-            vt_allow_big_lds((const void*)k_gemm_nt_lds<false, 2>, attr[2], mx) != VT_OK ||
-            vt_allow_big_lds((const void*)k_gemm_nt_lds<true, 2>, attr[3], mx) != VT_OK)
+        constexpr int kStageBytes128 = 2 * (kKC / 2) * kT * 2 * (int)sizeof(double);          // 32 KB
+        constexpr int kStageBytes256 = (kKC / 2) * (256 + kT) * 2 * (int)sizeof(double);      // 48 KB
+        static VtLdsAttr attr[5];
+        if (vt_allow_big_lds((const void*)k_gemm_nt_lds<false, 3, 128>, attr[0], 3 * kStageBytes128) != VT_OK ||
+            vt_allow_big_lds((const void*)k_gemm_nt_lds<true, 3, 128>, attr[1], 3 * kStageBytes128) != VT_OK ||
+            vt_allow_big_lds((const void*)k_gemm_nt_lds<false, 2, 128>, attr[2], 3 * kStageBytes128) != VT_OK ||
+            vt_allow_big_lds((const void*)k_gemm_nt_lds<true, 2, 128>, attr[3], 3 * kStageBytes128) != VT_OK ||
+            vt_allow_big_lds((const void*)k_gemm_nt_lds<false, 3, 256, kTallWaves>, attr[4], 3 * kStageBytes256) != VT_OK)
             return VT_ERR_HIP;
+        // tall products (the blocked TRSM's updates: M = N rows, one 128-column block): 256-row tiles once they
+        // fill the chip a few times over
+        if (!lower && large_tall_tiles() && M >= (int64_t)256 * 4 * num_cu()) {
+            dim3 grid2((unsigned)((M + 255) / 256), (unsigned)((N + kT - 1) / kT));
+            hipLaunchKernelGGL((k_gemm_nt_lds<false, 3, 256, kTallWaves>), grid2, dim3(kTallWaves * 64), 3 * kStageBytes256, st, a);
+            return vt_launch_status();
+        }
+        const size_t shmem = (size_t)stages * kStageBytes128;   // 96 / 64 KB
         if (stages == 2) {
-            if (lower) hipLaunchKernelGGL((k_gemm_nt_lds<true, 2>), grid, dim3(512), shmem, st, a);
-            else hipLaunchKernelGGL((k_gemm_nt_lds<false, 2>), grid, dim3(512), shmem, st, a);
+            if (lower) hipLaunchKernelGGL((k_gemm_nt_lds<true, 2, 128>), grid, dim3(512), shmem, st, a);
+            else hipLaunchKernelGGL((k_gemm_nt_lds<false, 2, 128>), grid, dim3(512), shmem, st, a);
         } else {
-            if (lower) hipLaunchKernelGGL((k_gemm_nt_lds<true, 3>), grid, dim3(512), shmem, st, a);
-            else hipLaunchKernelGGL((k_gemm_nt_lds<false, 3>), grid, dim3(512), shmem, st, a);
+            if (lower) hipLaunchKernelGGL((k_gemm_nt_lds<true, 3, 128>), grid, dim3(512), shmem, st, a);
+            else hipLaunchKernelGGL((k_gemm_nt_lds<false, 3, 128>), grid, dim3(512), shmem, st, a);
         }
         return vt_launch_status();
     }
