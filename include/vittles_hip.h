@@ -274,6 +274,22 @@ int    vt_glm_value_f32(int family, const float* X_dev, int64_t ldx, const doubl
                         const double* y_dev, const double* w_dev, const double* offset_dev, double scale,
                         int64_t N, int D, double* value_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* ---- Synthetic inputs: counter-based generator ----------------------------------
+ * Philox-4x32-10, key = seed, counter = (row, column pair, stream_id): any block of rows can be regenerated
+ * independently (row shards of one global data set; host-side spot checks -- vittles_amd/synth.py implements the
+ * same generator in NumPy, identical bits, normal transform equal to a few ulps).  No counterpart in the reference,
+ * whose tests draw from np.random with fixed seeds (vittles/tests/test_sensitivity_lib.py:463-478).
+ * vt_synth_normal: X[n][j] ~ N(0,1) for rows row0 .. row0+N-1 of the global matrix (Box-Muller of the two uniforms
+ *   of counter (row0 + n, j / 2, stream_id); stream_id 0 = design matrix, 1 = responses, 2 = theta*).
+ * vt_synth_response: y_n from z_n = x_n . theta* and the uniforms of counter (row0 + n, 0, 1):
+ *   logistic 1{u < sigmoid(z)}; poisson: inverse CDF of Poisson(exp(z)); gaussian z + N(0,1). */
+int    vt_synth_normal(uint64_t seed, unsigned stream_id, int64_t row0, int64_t N, int D, double* X_dev,
+                       int64_t ldx, void* stream);
+int    vt_synth_normal_f32(uint64_t seed, unsigned stream_id, int64_t row0, int64_t N, int D, float* X_dev,
+                           int64_t ldx, void* stream);
+int    vt_synth_response(uint64_t seed, int64_t row0, int64_t N, int family, const double* z_dev, double* y_dev,
+                         void* stream);
+
 /* ---- K6 driver: the BLAS-1 part of one CG iteration, fused into one launch -------------
  * Replaces: the loop body of scipy.sparse.linalg.cg as called by
  *             vittles/solver_lib.py:91-97 (SciPy _isolve/iterative.py: rho = r.r;

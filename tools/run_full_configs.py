@@ -30,21 +30,17 @@ def note(msg):
     print("[%.1fs] %s" % (time.perf_counter() - T0, msg), flush=True)
 
 
+SEED_C3 = 3
+
+
 def rel(a, b):
     return float(np.abs(a - b).max() / np.abs(b).max())
 
 
-def gen(N, D, seed, chunk=250_000):
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    X = torch.empty((N, D), dtype=torch.float64, device=dev)
-    theta_star = torch.randn(D, dtype=torch.float64, device=dev, generator=g) / D ** 0.5
-    y = torch.empty(N, dtype=torch.float64, device=dev)
-    for s in range(0, N, chunk):
-        e = min(N, s + chunk)
-        torch.randn((e - s, D), dtype=torch.float64, device=dev, generator=g, out=X[s:e])
-        z = rows.gemv(X[s:e], theta_star)
-        y[s:e] = (torch.rand(e - s, dtype=torch.float64, device=dev, generator=g) < torch.sigmoid(z)).double()
+def gen(N, D, seed):
+    """The counter-based generator (vittles_amd/synth.py): the data set exists only in HBM, any row block can be
+    regenerated on the host for the checks below."""
+    X, y, _ = va.synth.glm_problem(N, D, "logistic", seed=seed, device=dev)
     return X, y
 
 
@@ -61,7 +57,7 @@ def timed(fn):
 def config3(scale):
     N, D = int(10_000_000 * scale), 1000
     note("c3: generating X (%d x %d, %.1f GB)" % (N, D, 8e-9 * N * D))
-    X, y = gen(N, D, seed=3)
+    X, y = gen(N, D, seed=SEED_C3)
     w = torch.ones(N, dtype=torch.float64, device=dev)
     obj = va.WeightedGLMObjective(X, y, family="logistic", prior=1.0)
     t0 = time.perf_counter()
@@ -91,8 +87,9 @@ def config3(scale):
     th = theta.cpu().numpy()
     cf = scipy.linalg.cho_factor(Hh)
     idx = torch.randint(0, N, (2000,), device=dev, generator=torch.Generator(device=dev).manual_seed(7))
-    Xs = X[idx].cpu().numpy()
-    ys = y[idx].cpu().numpy()
+    # the sampled rows are REGENERATED on the host from the counter-based seed, not copied from the device
+    Xs, ys = va.synth.glm_rows_host(N, D, "logistic", SEED_C3, idx.cpu().numpy())
+    res["regenerated_rows_max_abs_diff"] = float(np.abs(X[idx].cpu().numpy() - Xs).max())
     p = 1.0 / (1.0 + np.exp(-(Xs @ th)))
     S_ref = -scipy.linalg.cho_solve(cf, (Xs * (p - ys)[:, None]).T).T
     res["S_sampled_rows_rel_err"] = rel(S[idx].cpu().numpy(), S_ref)
@@ -123,7 +120,7 @@ def config3(scale):
 def config4(scale):
     N, D = int(500_000 * scale), 20_000
     note("c4: generating X (%d x %d, %.1f GB)" % (N, D, 8e-9 * N * D))
-    X, y = gen(N, D, seed=4, chunk=20_000)
+    X, y = gen(N, D, seed=4)
     w = torch.ones(N, dtype=torch.float64, device=dev)
     prior = 1.0
     obj = va.WeightedGLMObjective(X, y, family="logistic", prior=prior)

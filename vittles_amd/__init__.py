@@ -10,6 +10,7 @@ from .sparse_hessian_lib import SparseBlockHessian
 from .lr_cov_lib import LinearResponseCovariances
 from . import solver_lib
 from . import optim
+from . import synth
 from . import bivariate_sensitivity_lib
 
 

@@ -93,6 +93,9 @@ SIGNATURES = {
     "vt_gemv_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size_t, c_ptr]),
     "vt_glm_value_f32": (c_int, [c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_i64, c_int,
                                  c_ptr, c_ptr, c_size_t, c_ptr]),
+    "vt_synth_normal": (c_int, [ctypes.c_uint64, ctypes.c_uint, c_i64, c_i64, c_int, c_ptr, c_i64, c_ptr]),
+    "vt_synth_normal_f32": (c_int, [ctypes.c_uint64, ctypes.c_uint, c_i64, c_i64, c_int, c_ptr, c_i64, c_ptr]),
+    "vt_synth_response": (c_int, [ctypes.c_uint64, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
 }
 
 _lib = None
