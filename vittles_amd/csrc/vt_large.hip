@@ -146,14 +146,28 @@ __device__ __forceinline__ void lg_wait4_barrier() {
 //             CU.  Per stage the DMA brings (TM + 128) x 16 doubles for 2 TM 128 16 flops: 16 flop/B at TM = 128
 //             (8 B/cycle/CU at the MFMA peak, two thirds of what LDS-DMA delivers, MI355X_MICROARCH.md price
 //             list) and 21 flop/B at TM = 256 -- and 8 operand reads feed 16 MFMAs instead of 6 feeding 8.
+//
+// VT_GEMM_LINES (default): a DMA instruction moves 8 rows x 16 k -- lane 8 kp + r reads the kp-th 16-byte piece of
+// row r, so the 8 lanes of a row ask for ONE contiguous 128-byte line, once per stage.  (The first layout had every
+// lane of an instruction read 16 bytes of a DIFFERENT row and eight instructions of different waves come back for
+// the other pieces of each line: 64 line requests per KB moved.)  LDS image per 8-row block: [kp 8][row 8][2 k]
+// = 1 KB, blocks 1152 bytes apart, so that the 32 lanes of a half wave (16 rows x 2 k) hit 64 different banks.
+#ifndef VT_GEMM_LINES
+#define VT_GEMM_LINES 1
+#endif
+constexpr bool kLines = VT_GEMM_LINES != 0;
+constexpr int kRB = 144;   // doubles between the LDS images of consecutive 8-row blocks (1 KB + 128 B)
+
 template <bool LOWER, int STAGES, int TM, int WAVES = 8>
 __global__ __launch_bounds__(WAVES * 64) void k_gemm_nt_lds(GemmArgs a) {
     if (LOWER && blockIdx.y > blockIdx.x) return;
-    extern __shared__ double lds[];            // [STAGES][A: 8 planes x TM rows x 2 | B: 8 planes x 128 rows x 2]
+    extern __shared__ double lds[];            // [STAGES][A panel | B panel]
     constexpr int WM = TM / 64, WN = WAVES / WM;   // wave grid
     constexpr int NJ = kT / WN / 16;           // 16-column blocks per wave
-    constexpr int PA = (kKC / 2) * TM * 2, PB = (kKC / 2) * kT * 2, STAGE = PA + PB;
-    constexpr int NDMA = (kKC / 2) * (TM / 64 + kT / 64);   // DMA instructions per stage
+    constexpr int PA = kLines ? (TM / 8) * kRB : (kKC / 2) * TM * 2;
+    constexpr int PB = kLines ? (kT / 8) * kRB : (kKC / 2) * kT * 2;
+    constexpr int STAGE = PA + PB;
+    constexpr int NDMA = kLines ? (TM / 8 + kT / 8) : (kKC / 2) * (TM / 64 + kT / 64);   // DMA instructions per stage
     constexpr int PER_WAVE = NDMA / WAVES;
     static_assert(NDMA % WAVES == 0 && (PER_WAVE == 3 || PER_WAVE == 4 || PER_WAVE == 6), "DMA split");
     const int lane = threadIdx.x & 63;
@@ -165,8 +179,36 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_nt_lds(GemmArgs a) {
     const int mrem = (int)min((int64_t)TM, a.M - m0), nrem = min(kT, a.N - n0);
     const int nk = (a.K + kKC - 1) / kKC;
 
+    // lane 8 kp + r of a line-wise DMA instruction: row r of the block, k pair kp
+    const unsigned voffA = (unsigned)(((lane & 7) * a.lda + 2 * (lane >> 3)) * 8);
+    const unsigned voffB = (unsigned)(((lane & 7) * a.ldb + 2 * (lane >> 3)) * 8);
+    const int ktail = a.K - (nk - 1) * kKC;    // k of the last stage (16 unless K is not a multiple of 16)
+    const bool lane_in_tail = 2 * (lane >> 3) < ktail;
+
     // this wave's DMA instructions of a stage: ids wave*PER_WAVE .. of NDMA (A first, then B)
     auto issue = [&](int t, int buf) {
+        if constexpr (kLines) {
+            const bool tail = t == nk - 1 && ktail < kKC;   // uniform
+#pragma unroll
+            for (int e = 0; e < PER_WAVE; ++e) {
+                const int id = wave * PER_WAVE + e;
+                constexpr int NA = TM / 8;
+                const bool isb = id >= NA;
+                const int blk = isb ? id - NA : id;
+                const int rem = isb ? nrem : mrem;
+                const int64_t ld = isb ? a.ldb : a.lda;
+                const double* base = (isb ? a.B + (int64_t)n0 * a.ldb : a.A + m0 * a.lda) + t * kKC;
+                // rows past the tile read 0 (range check); k past K: the lanes of those pieces are sent out of range
+                const int kv = tail ? ktail : kKC;
+                const unsigned bytes = t < nk ? (unsigned)(((int64_t)(rem - 1) * ld + kv) * 8) : 0u;
+                unsigned voff = isb ? voffB : voffA;
+                if (tail) voff = lane_in_tail ? voff : 0x7ffffff0u;
+                double* dst = lds + buf * STAGE + (isb ? PA : 0) + blk * kRB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(lg_rsrc(base, bytes), (vt_ldsptr)dst, 16, voff,
+                                                         (unsigned)(blk * 8 * ld) * 8u, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < PER_WAVE; ++e) {
             const int id = wave * PER_WAVE + e;
@@ -210,15 +252,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemm_nt_lds(GemmArgs a) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (!(VT_LABL & 1)) issue(t + 1, buf ^ 1);
         }
-        const double* pa = lds + buf * STAGE + (q >> 1) * (TM * 2) + (64 * wm + c) * 2 + (q & 1);
-        const double* pb = lds + buf * STAGE + PA + (q >> 1) * (kT * 2) + (16 * NJ * wn + c) * 2 + (q & 1);
+        // operand of lane (c = row, q = k) for k-step s: plane kp = 2 s + (q >> 1), element q & 1
+        const double* pa = kLines ? lds + buf * STAGE + (8 * wm + (c >> 3)) * kRB + (q >> 1) * 16 + (c & 7) * 2 + (q & 1)
+                                  : lds + buf * STAGE + (q >> 1) * (TM * 2) + (64 * wm + c) * 2 + (q & 1);
+        const double* pb = kLines ? lds + buf * STAGE + PA + (2 * NJ * wn + (c >> 3)) * kRB + (q >> 1) * 16 + (c & 7) * 2 + (q & 1)
+                                  : lds + buf * STAGE + PA + (q >> 1) * (kT * 2) + (16 * NJ * wn + c) * 2 + (q & 1);
+        constexpr int SA = kLines ? 32 : 2 * (TM * 2), SB = kLines ? 32 : 2 * (kT * 2);   // doubles per k-step
+        constexpr int BI = kLines ? 2 * kRB : 32;                                          // doubles per 16 rows
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             double af[4], bf[NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = pa[2 * s * (TM * 2) + 32 * i];
+            for (int i = 0; i < 4; ++i) af[i] = pa[s * SA + BI * i];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bf[j] = pb[2 * s * (kT * 2) + 32 * j];
+            for (int j = 0; j < NJ; ++j) bf[j] = pb[s * SB + BI * j];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -265,6 +312,7 @@ static int large_stages() {
 #ifndef VT_TALL_WAVES
 #define VT_TALL_WAVES 16
 #endif
+constexpr int kTallStages = kLines ? 2 : 3;   // 3 line-wise stages of a 256-row tile (162 KB) do not fit the LDS
 constexpr int kTallWaves = VT_TALL_WAVES;   // waves of a 256 x 128 tile: 16 (4 x 4 of 64 x 32) or 8 (4 x 2 of 64 x 64)
 
 // 256 x 128 tiles for the tall products are OFF by default: measured at N = 1.25e6, D = 1000 (whole blocked TRSM,
@@ -291,20 +339,22 @@ int gemm_nt(double* C, int64_t ldc, int64_t M, int N, const double* A, int64_t l
     dim3 grid((unsigned)((M + kT - 1) / kT), (unsigned)((N + kT - 1) / kT));
     if (lds_path_ok(A, lda, B, ldb, K)) {
         const int stages = large_stages();
-        constexpr int kStageBytes128 = 2 * (kKC / 2) * kT * 2 * (int)sizeof(double);          // 32 KB
-        constexpr int kStageBytes256 = (kKC / 2) * (256 + kT) * 2 * (int)sizeof(double);      // 48 KB
+        constexpr int kStageBytes128 = (kLines ? 2 * (kT / 8) * kRB : 2 * (kKC / 2) * kT * 2) * (int)sizeof(double);   // 36 / 32 KB
+        constexpr int kStageBytes256 = (kLines ? ((256 + kT) / 8) * kRB : (kKC / 2) * (256 + kT) * 2) * (int)sizeof(double);
         static VtLdsAttr attr[5];
         if (vt_allow_big_lds((const void*)k_gemm_nt_lds<false, 3, 128>, attr[0], 3 * kStageBytes128) != VT_OK ||
             vt_allow_big_lds((const void*)k_gemm_nt_lds<true, 3, 128>, attr[1], 3 * kStageBytes128) != VT_OK ||
             vt_allow_big_lds((const void*)k_gemm_nt_lds<false, 2, 128>, attr[2], 3 * kStageBytes128) != VT_OK ||
             vt_allow_big_lds((const void*)k_gemm_nt_lds<true, 2, 128>, attr[3], 3 * kStageBytes128) != VT_OK ||
-            vt_allow_big_lds((const void*)k_gemm_nt_lds<false, 3, 256, kTallWaves>, attr[4], 3 * kStageBytes256) != VT_OK)
+            vt_allow_big_lds((const void*)k_gemm_nt_lds<false, kTallStages, 256, kTallWaves>, attr[4],
+                             kTallStages * kStageBytes256) != VT_OK)
             return VT_ERR_HIP;
         // tall products (the blocked TRSM's updates: M = N rows, one 128-column block): 256-row tiles once they
         // fill the chip a few times over
         if (!lower && large_tall_tiles() && M >= (int64_t)256 * 4 * num_cu()) {
             dim3 grid2((unsigned)((M + 255) / 256), (unsigned)((N + kT - 1) / kT));
-            hipLaunchKernelGGL((k_gemm_nt_lds<false, 3, 256, kTallWaves>), grid2, dim3(kTallWaves * 64), 3 * kStageBytes256, st, a);
+            hipLaunchKernelGGL((k_gemm_nt_lds<false, kTallStages, 256, kTallWaves>), grid2, dim3(kTallWaves * 64),
+                               kTallStages * kStageBytes256, st, a);
             return vt_launch_status();
         }
         const size_t shmem = (size_t)stages * kStageBytes128;   // 96 / 64 KB
