@@ -138,163 +138,131 @@ __device__ __forceinline__ void lg_wait4_barrier() {
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// C = beta C + alpha A B^T.  LDS panel layout [k/2][row][2]: one DMA instruction moves (64 rows) x
-// (2 k) and MFMA operand reads (lane = row, k) are bank-conflict free.
-// TM x 128 output tile per workgroup, 8 waves (2 per SIMD):
-//   TM = 128: 2 x 4 waves of 64 x 32.  32 KB per stage; with 2 stages two workgroups share a CU.
-//   TM = 256: 4 x 2 waves of 64 x 64 (128 accumulator registers).  48 KB per stage, 3 stages, one workgroup per
-//             CU.  Per stage the DMA brings (TM + 128) x 16 doubles for 2 TM 128 16 flops: 16 flop/B at TM = 128
-//             (8 B/cycle/CU at the MFMA peak, two thirds of what LDS-DMA delivers, MI355X_MICROARCH.md price
-//             list) and 21 flop/B at TM = 256 -- and 8 operand reads feed 16 MFMAs instead of 6 feeding 8.
-//
-// VT_GEMM_LINES (default): a DMA instruction moves 8 rows x 16 k -- lane 8 kp + r reads the kp-th 16-byte piece of
-// row r, so the 8 lanes of a row ask for ONE contiguous 128-byte line, once per stage.  (The first layout had every
-// lane of an instruction read 16 bytes of a DIFFERENT row and eight instructions of different waves come back for
-// the other pieces of each line: 64 line requests per KB moved.)  LDS image per 8-row block: [kp 8][row 8][2 k]
-// = 1 KB, blocks 1152 bytes apart, so that the 32 lanes of a half wave (16 rows x 2 k) hit 64 different banks.
-#ifndef VT_GEMM_LINES
-#define VT_GEMM_LINES 1
-#endif
-constexpr bool kLines = VT_GEMM_LINES != 0;
+// C = beta C + alpha A B^T on 128 x 128 output tiles: 8 waves (2 per SIMD) of 64 x 32, two stages of 16 k (72 KB of
+// LDS, so two workgroups share a CU and cover each other's barrier and DMA waits: +9-12 % over a 3-stage single
+// workgroup).
+//   * LINE-WISE DMA: one instruction moves 8 rows x 16 k -- lane 8 kp + r reads the kp-th 16-byte piece of row r, so
+//     the 8 lanes of a row ask for ONE contiguous 128-byte line, once per stage.  (The first layout had every lane of
+//     an instruction read 16 bytes of a DIFFERENT row and eight instructions of different waves come back for the other
+//     pieces of each line: 64 line requests per KB moved; blocked TRSM at N = 1.25e6, D = 1000: 53.3 -> 49.5 ms.)
+//     LDS image per 8-row block: [kp 8][row 8][2 k] = 1 KB, blocks 1152 bytes apart, so that the 32 lanes of a half
+//     wave (16 rows x 2 k) hit 64 different banks when they read MFMA operands (lane = row, k).
+//   * PERSISTENT over the row tiles of a tall product (the blocked TRSM's updates: M = N rows): the workgroup walks
+//     tiles blockIdx.x, + gridDim.x, ... and issues stage 0 of the NEXT tile during the last stage of the current one,
+//     so the epilogue's stores and the next prologue's DMA latency overlap instead of idling the MFMA pipe twice
+//     per tile (K is as short as 128 for the first column blocks: 8 stages per tile).
+// 256 x 128 tiles (8 waves of 64 x 64, or 16 waves of 64 x 32) were built and measured SLOWER (66.0 / 56.4 ms
+// against 53.6 for the same layout): one workgroup per CU has nobody to fill the MFMA pipe while all its waves
+// re-read their operands after the stage barrier.  DESIGN.md section 8.
 constexpr int kRB = 144;   // doubles between the LDS images of consecutive 8-row blocks (1 KB + 128 B)
+constexpr int kGemmStage = 2 * (kT / 8) * kRB;                          // doubles per stage (A panel + B panel)
+constexpr int kGemmLdsBytes = 2 * kGemmStage * (int)sizeof(double);     // 73 728
 
-template <bool LOWER, int STAGES, int TM, int WAVES = 8>
-__global__ __launch_bounds__(WAVES * 64) void k_gemm_nt_lds(GemmArgs a) {
-    if (LOWER && blockIdx.y > blockIdx.x) return;
-    extern __shared__ double lds[];            // [STAGES][A panel | B panel]
-    constexpr int WM = TM / 64, WN = WAVES / WM;   // wave grid
-    constexpr int NJ = kT / WN / 16;           // 16-column blocks per wave
-    constexpr int PA = kLines ? (TM / 8) * kRB : (kKC / 2) * TM * 2;
-    constexpr int PB = kLines ? (kT / 8) * kRB : (kKC / 2) * kT * 2;
-    constexpr int STAGE = PA + PB;
-    constexpr int NDMA = kLines ? (TM / 8 + kT / 8) : (kKC / 2) * (TM / 64 + kT / 64);   // DMA instructions per stage
-    constexpr int PER_WAVE = NDMA / WAVES;
-    static_assert(NDMA % WAVES == 0 && (PER_WAVE == 3 || PER_WAVE == 4 || PER_WAVE == 6), "DMA split");
+template <bool LOWER>
+__global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
+    if (LOWER && blockIdx.y > blockIdx.x) return;   // (LOWER products are launched one tile per workgroup)
+    extern __shared__ double lds[];            // [2 stages][A panel | B panel]
+    constexpr int PA = (kT / 8) * kRB;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = wave >> 2, wn = wave & 3;   // 2 x 4 waves of 64 x 32
     const int q = lane >> 4, c = lane & 15;
-    const int64_t m0 = (int64_t)blockIdx.x * TM;
     const int n0 = blockIdx.y * kT;
-    const int mrem = (int)min((int64_t)TM, a.M - m0), nrem = min(kT, a.N - n0);
+    const int nrem = min(kT, a.N - n0);
     const int nk = (a.K + kKC - 1) / kKC;
+    const int64_t ntiles = (a.M + kT - 1) / kT;
 
-    // lane 8 kp + r of a line-wise DMA instruction: row r of the block, k pair kp
+    // lane 8 kp + r of a DMA instruction: row r of the block, k pair kp
     const unsigned voffA = (unsigned)(((lane & 7) * a.lda + 2 * (lane >> 3)) * 8);
     const unsigned voffB = (unsigned)(((lane & 7) * a.ldb + 2 * (lane >> 3)) * 8);
     const int ktail = a.K - (nk - 1) * kKC;    // k of the last stage (16 unless K is not a multiple of 16)
     const bool lane_in_tail = 2 * (lane >> 3) < ktail;
 
-    // this wave's DMA instructions of a stage: ids wave*PER_WAVE .. of NDMA (A first, then B)
-    auto issue = [&](int t, int buf) {
-        if constexpr (kLines) {
-            const bool tail = t == nk - 1 && ktail < kKC;   // uniform
+    // this wave's 4 DMA instructions of stage t of row tile `tile`: ids wave*4 .. wave*4+3 of 32 (A first, then B)
+    auto issue = [&](int64_t tile, int t, int buf) {
+        const bool tail = t == nk - 1 && ktail < kKC;   // uniform
+        const int64_t m0 = tile * kT;
+        const int mrem = (int)min((int64_t)kT, a.M - m0);
 #pragma unroll
-            for (int e = 0; e < PER_WAVE; ++e) {
-                const int id = wave * PER_WAVE + e;
-                constexpr int NA = TM / 8;
-                const bool isb = id >= NA;
-                const int blk = isb ? id - NA : id;
-                const int rem = isb ? nrem : mrem;
-                const int64_t ld = isb ? a.ldb : a.lda;
-                const double* base = (isb ? a.B + (int64_t)n0 * a.ldb : a.A + m0 * a.lda) + t * kKC;
-                // rows past the tile read 0 (range check); k past K: the lanes of those pieces are sent out of range
-                const int kv = tail ? ktail : kKC;
-                const unsigned bytes = t < nk ? (unsigned)(((int64_t)(rem - 1) * ld + kv) * 8) : 0u;
-                unsigned voff = isb ? voffB : voffA;
-                if (tail) voff = lane_in_tail ? voff : 0x7ffffff0u;
-                double* dst = lds + buf * STAGE + (isb ? PA : 0) + blk * kRB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(lg_rsrc(base, bytes), (vt_ldsptr)dst, 16, voff,
-                                                         (unsigned)(blk * 8 * ld) * 8u, 0, 0);
-            }
-            return;
-        }
-#pragma unroll
-        for (int e = 0; e < PER_WAVE; ++e) {
-            const int id = wave * PER_WAVE + e;
-            constexpr int NA = (kKC / 2) * (TM / 64);
-            const bool isb = id >= NA;
-            const int idl = isb ? id - NA : id;
-            const int parts = isb ? kT / 64 : TM / 64;
-            const int kp = idl / parts, part = idl % parts;
-            const int k0 = t * kKC + 2 * kp;
+        for (int e = 0; e < 4; ++e) {
+            const int id = wave * 4 + e;
+            const bool isb = id >= kT / 8;
+            const int blk = id & (kT / 8 - 1);
             const int rem = isb ? nrem : mrem;
             const int64_t ld = isb ? a.ldb : a.lda;
-            const double* base = (isb ? a.B + (int64_t)n0 * a.ldb : a.A + m0 * a.lda) + k0;
-            // rows past the tile and k past K read 0
-            const unsigned bytes = (t < nk && k0 < a.K) ? (unsigned)(((int64_t)(rem - 1) * ld + 2) * 8) : 0u;
-            double* dst = lds + buf * STAGE + (isb ? PA + kp * (kT * 2) : kp * (TM * 2)) + part * 128;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(lg_rsrc(base, bytes), (vt_ldsptr)dst, 16,
-                                                     (unsigned)((64 * part + lane) * ld) * 8u, 0, 0, 0);
+            const double* base = (isb ? a.B + (int64_t)n0 * a.ldb : a.A + m0 * a.lda) + t * kKC;
+            // rows past the tile read 0 (range check); k past K: the lanes of those pieces are sent out of range
+            const int kv = tail ? ktail : kKC;
+            const unsigned bytes = (unsigned)(((int64_t)(rem - 1) * ld + kv) * 8);
+            unsigned voff = isb ? voffB : voffA;
+            if (tail) voff = lane_in_tail ? voff : 0x7ffffff0u;
+            double* dst = lds + buf * kGemmStage + (isb ? PA : 0) + blk * kRB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(lg_rsrc(base, bytes), (vt_ldsptr)dst, 16, voff,
+                                                     (unsigned)(blk * 8 * ld) * 8u, 0, 0);
         }
     };
 
-    f64x4 acc[4][NJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
-
-    issue(0, 0);
-    if constexpr (STAGES == 3) issue(1, 1);
+    int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    issue(tile, 0, 0);
     int buf = 0;
-    for (int t = 0; t < nk; ++t) {
-        if constexpr (STAGES == 3) {
-            // the stage about to be used has landed (only the newest PER_WAVE DMA instructions of this wave may
-            // still be in flight), then everybody's part of it
-            if constexpr (PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else if constexpr (PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const int b2 = buf == 0 ? 2 : buf - 1;     // (buf + 2) % 3
-            if (!(VT_LABL & 1)) issue(t + 2, b2);
-        } else {
-            // two stages (64 KB): two workgroups per CU cover each other's waits
+    while (true) {
+        const int64_t next = tile + gridDim.x;
+        f64x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+        for (int t = 0; t < nk; ++t) {
+            // the stage about to be used has landed, everybody's part of it; then the DMA of the stage after it
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (!(VT_LABL & 1)) issue(t + 1, buf ^ 1);
+            if (!(VT_LABL & 1)) {
+                if (t + 1 < nk) issue(tile, t + 1, buf ^ 1);
+                else if (next < ntiles) issue(next, 0, buf ^ 1);
+            }
+            // operand of lane (c = row, q = k) for k-step s: plane kp = 2 s + (q >> 1), element q & 1
+            const double* pa = lds + buf * kGemmStage + (8 * wm + (c >> 3)) * kRB + (q >> 1) * 16 + (c & 7) * 2 + (q & 1);
+            const double* pb = lds + buf * kGemmStage + PA + (4 * wn + (c >> 3)) * kRB + (q >> 1) * 16 + (c & 7) * 2 + (q & 1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                double af[4], bf[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = pa[s * 32 + 2 * kRB * i];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = pb[s * 32 + 2 * kRB * j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (VT_LABL & 2) acc[i][j][0] += af[i] * bf[j]; else
+                        acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+                    }
+            }
+            buf ^= 1;
         }
-        // operand of lane (c = row, q = k) for k-step s: plane kp = 2 s + (q >> 1), element q & 1
-        const double* pa = kLines ? lds + buf * STAGE + (8 * wm + (c >> 3)) * kRB + (q >> 1) * 16 + (c & 7) * 2 + (q & 1)
-                                  : lds + buf * STAGE + (q >> 1) * (TM * 2) + (64 * wm + c) * 2 + (q & 1);
-        const double* pb = kLines ? lds + buf * STAGE + PA + (2 * NJ * wn + (c >> 3)) * kRB + (q >> 1) * 16 + (c & 7) * 2 + (q & 1)
-                                  : lds + buf * STAGE + PA + (q >> 1) * (kT * 2) + (16 * NJ * wn + c) * 2 + (q & 1);
-        constexpr int SA = kLines ? 32 : 2 * (TM * 2), SB = kLines ? 32 : 2 * (kT * 2);   // doubles per k-step
-        constexpr int BI = kLines ? 2 * kRB : 32;                                          // doubles per 16 rows
+        // epilogue of this tile (the next tile's first stage is in flight)
+        const int64_t m0 = tile * kT;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            double af[4], bf[NJ];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = pa[s * SA + BI * i];
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + 32 * wn + 16 * j + c;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bf[j] = pb[s * SB + BI * j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    if (VT_LABL & 2) acc[i][j][0] += af[i] * bf[j]; else
-                    acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
-                }
-        }
-        if constexpr (STAGES == 3) buf = buf == 2 ? 0 : buf + 1;
-        else buf ^= 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-filled look-ahead stages
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + 16 * NJ * wn + 16 * j + c;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t m = m0 + 64 * wm + 16 * i + q + 4 * r;
-                if (m < a.M && n < a.N) {
-                    double* p = a.C + m * a.ldc + n;
-                    double v = a.alpha * acc[i][j][r];
-                    if (a.Csrc) v = fma(a.cscale * (a.rowscale ? a.rowscale[m] : 1.0), a.Csrc[m * a.ldcs + n], v);
-                    else if (a.beta != 0.0) v = fma(a.beta, *p, v);
-                    *p = v;
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t m = m0 + 64 * wm + 16 * i + q + 4 * r;
+                    if (m < a.M && n < a.N) {
+                        double* p = a.C + m * a.ldc + n;
+                        double v = a.alpha * acc[i][j][r];
+                        if (a.Csrc) v = fma(a.cscale * (a.rowscale ? a.rowscale[m] : 1.0), a.Csrc[m * a.ldcs + n], v);
+                        else if (a.beta != 0.0) v = fma(a.beta, *p, v);
+                        *p = v;
+                    }
                 }
             }
-        }
+        if (next >= ntiles) break;
+        tile = next;
+    }
 }
 
 // dev switches, read ONCE per process (never on the hot path)
@@ -304,26 +272,9 @@ static bool large_no_lds() {
 }
 
 static int large_stages() {
-    // default 2: measured 48.6 vs 43.2 TFLOP/s (SYRK, N = 1.25e6, D = 1000); VT_LARGE_STAGES=3 for A/B runs
+    // SYRK stages, default 2: measured 48.6 vs 43.2 TFLOP/s (N = 1.25e6, D = 1000); VT_LARGE_STAGES=3 for A/B runs
     static const int st = getenv("VT_LARGE_STAGES") ? atoi(getenv("VT_LARGE_STAGES")) : 2;
     return st == 3 ? 3 : 2;
-}
-
-#ifndef VT_TALL_WAVES
-#define VT_TALL_WAVES 16
-#endif
-constexpr int kTallStages = kLines ? 2 : 3;   // 3 line-wise stages of a 256-row tile (162 KB) do not fit the LDS
-constexpr int kTallWaves = VT_TALL_WAVES;   // waves of a 256 x 128 tile: 16 (4 x 4 of 64 x 32) or 8 (4 x 2 of 64 x 64)
-
-// 256 x 128 tiles for the tall products are OFF by default: measured at N = 1.25e6, D = 1000 (whole blocked TRSM,
-// tools/time_trsm_large.py) 53.6 ms with 128-row tiles (two workgroups per CU), 66.0 ms with 8 waves of 64 x 64
-// and 56.4 ms with 16 waves of 64 x 32 on 256-row tiles: one workgroup per CU has nobody to fill the MFMA pipe
-// while all its waves re-read their operands after the stage barrier (without any DMA the three read 45.7 /
-// 58.0 / 54.4 ms), which costs more than the 25 % of LDS-DMA traffic the taller tile saves.
-// VT_LARGE_TM256=1 turns them on for A/B runs.
-static bool large_tall_tiles() {
-    static const bool v = getenv("VT_LARGE_TM256") != nullptr;
-    return v;
 }
 
 bool lds_path_ok(const double* A, int64_t lda, const double* B, int64_t ldb, int K) {
@@ -338,32 +289,16 @@ int gemm_nt(double* C, int64_t ldc, int64_t M, int N, const double* A, int64_t l
     GemmArgs a{C, ldc, M, N, A, lda, B, ldb, K, alpha, beta, Csrc, ldcs, rowscale, cscale};
     dim3 grid((unsigned)((M + kT - 1) / kT), (unsigned)((N + kT - 1) / kT));
     if (lds_path_ok(A, lda, B, ldb, K)) {
-        const int stages = large_stages();
-        constexpr int kStageBytes128 = (kLines ? 2 * (kT / 8) * kRB : 2 * (kKC / 2) * kT * 2) * (int)sizeof(double);   // 36 / 32 KB
-        constexpr int kStageBytes256 = (kLines ? ((256 + kT) / 8) * kRB : (kKC / 2) * (256 + kT) * 2) * (int)sizeof(double);
-        static VtLdsAttr attr[5];
-        if (vt_allow_big_lds((const void*)k_gemm_nt_lds<false, 3, 128>, attr[0], 3 * kStageBytes128) != VT_OK ||
-            vt_allow_big_lds((const void*)k_gemm_nt_lds<true, 3, 128>, attr[1], 3 * kStageBytes128) != VT_OK ||
-            vt_allow_big_lds((const void*)k_gemm_nt_lds<false, 2, 128>, attr[2], 3 * kStageBytes128) != VT_OK ||
-            vt_allow_big_lds((const void*)k_gemm_nt_lds<true, 2, 128>, attr[3], 3 * kStageBytes128) != VT_OK ||
-            vt_allow_big_lds((const void*)k_gemm_nt_lds<false, kTallStages, 256, kTallWaves>, attr[4],
-                             kTallStages * kStageBytes256) != VT_OK)
+        static VtLdsAttr attr[2];
+        if (vt_allow_big_lds((const void*)k_gemm_nt_lds<false>, attr[0], kGemmLdsBytes) != VT_OK ||
+            vt_allow_big_lds((const void*)k_gemm_nt_lds<true>, attr[1], kGemmLdsBytes) != VT_OK)
             return VT_ERR_HIP;
-        // tall products (the blocked TRSM's updates: M = N rows, one 128-column block): 256-row tiles once they
-        // fill the chip a few times over
-        if (!lower && large_tall_tiles() && M >= (int64_t)256 * 4 * num_cu()) {
-            dim3 grid2((unsigned)((M + 255) / 256), (unsigned)((N + kT - 1) / kT));
-            hipLaunchKernelGGL((k_gemm_nt_lds<false, kTallStages, 256, kTallWaves>), grid2, dim3(kTallWaves * 64),
-                               kTallStages * kStageBytes256, st, a);
-            return vt_launch_status();
-        }
-        const size_t shmem = (size_t)stages * kStageBytes128;   // 96 / 64 KB
-        if (stages == 2) {
-            if (lower) hipLaunchKernelGGL((k_gemm_nt_lds<true, 2, 128>), grid, dim3(512), shmem, st, a);
-            else hipLaunchKernelGGL((k_gemm_nt_lds<false, 2, 128>), grid, dim3(512), shmem, st, a);
+        if (lower) {
+            hipLaunchKernelGGL((k_gemm_nt_lds<true>), grid, dim3(512), kGemmLdsBytes, st, a);
         } else {
-            if (lower) hipLaunchKernelGGL((k_gemm_nt_lds<true, 3, 128>), grid, dim3(512), shmem, st, a);
-            else hipLaunchKernelGGL((k_gemm_nt_lds<false, 3, 128>), grid, dim3(512), shmem, st, a);
+            // persistent over the row tiles: two workgroups per CU and column block
+            const unsigned gx = (unsigned)std::min<int64_t>(grid.x, std::max(1, 2 * num_cu() / (int)grid.y));
+            hipLaunchKernelGGL((k_gemm_nt_lds<false>), dim3(gx, grid.y), dim3(512), kGemmLdsBytes, st, a);
         }
         return vt_launch_status();
     }
