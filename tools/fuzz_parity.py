@@ -41,6 +41,18 @@ for it in range(cases):
     v = rng.standard_normal(D)
     from vittles_amd.cg import GLMHessianVectorProduct
     errs["hvp"] = rel(GLMHessianVectorProduct(obj, theta, w)(v), glm.hvp(fam, X, y, theta, w, v, prior, scale, offset))
+    if D <= 128:       # fp32 storage mode of the same case: 1e-4 against the fp64 oracle (scaled by the conditioning)
+        o32 = va.WeightedGLMObjective(Xd.to(torch.float32), y, family=fam, prior=prior, scale=scale, offset=offset,
+                                      dtype=torch.float32)
+        f32 = o32.fused(theta, w)
+        la32 = va.HyperparameterSensitivityLinearApproximation(o32, theta, w)
+        e32 = dict(H32=rel(f32["H"].cpu().numpy(), H_ref), S32=rel(la32.get_dopt_dhyper(), S_ref),
+                   g32=rel(o32.grad(theta, w).cpu().numpy(), g_ref))
+        c32 = np.linalg.cond(H_ref)
+        for k, e in e32.items():
+            worst[k] = max(worst.get(k, 0.0), e)
+            if e > max(1e-4, 1e-7 * c32) or e != e:
+                print("FAIL(fp32) case %d: N=%d D=%d %s cond=%.1e -> %s" % (it, N, D, fam, c32, e32), flush=True)
     cond = np.linalg.cond(H_ref)
     tolS = max(1e-10, 1e-15 * cond * 50)
     bad = [k for k, e in errs.items() if e > (tolS if k == "S" else 1e-10) or e != e]
