@@ -94,6 +94,18 @@ def glm_checks(rank, world, group, family, N, D):
     ds_ref = taylor.input_derivs(family, X, y, theta_ref, w, w_new - w, prior=prior, max_order=2)
     for k in range(2):
         assert rel(ds[k], ds_ref[k]) < 1e-9, ("taylor", k, rel(ds[k], ds_ref[k]))
+    # fp32 storage mode on the same shards (row n1): float X and S, all-reduced fp64 H, 1e-4
+    if D <= 128:
+        o32 = va.WeightedGLMObjective(X[a:b], y[a:b], family=family, prior=prior, process_group=group,
+                                      dtype=torch.float32)
+        la32 = va.HyperparameterSensitivityLinearApproximation(o32, theta_ref, w[a:b])
+        S32 = la32.get_dopt_dhyper()
+        assert S32.dtype == np.float32 and S32.shape == (D, b - a)
+        assert rel(la32.get_hessian_at_opt(), H_ref) < 1e-4
+        assert rel(S32, S_ref[:, a:b]) < 1e-4 * max(1.0, np.abs(S_ref).max() / np.abs(S_ref[:, a:b]).max())
+        assert rel(la32.predict_opt_par_from_hyper_par(w_new[a:b]), pred_ref) < 1e-4
+        th32, info32 = va.optim.newton_glm(o32, w[a:b], grad_tol=1e-9)
+        assert info32["converged"] and rel(th32, theta_ref) < 1e-4
     return dict(family=family, N=N, D=D, rows=(a, b))
 
 
