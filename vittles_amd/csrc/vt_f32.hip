@@ -11,238 +11,13 @@
 // kChunkSteps k-steps (4096 rows) into its f32 accumulators before they are folded into an fp64 slab in LDS:
 // the rounding error of a sum stays <= ~kChunkSteps * 2^-24 relative, whatever N is.
 #include "vt_common.h"
-#include <type_traits>
-#include <utility>
-#ifndef VT_ABL32
-#define VT_ABL32 0   // dev-only compile-time ablation mask (tools/build_dev32.sh): 1 no MFMA, 2 no link, 4 no loads in the loop
-#endif
+#include "vt_hess_stream.h"   // k_glm_hess_stream<float, ...>: the fused Hessian kernel shared with the narrow fp64 path
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-// v_mfma_f32_16x16x4_f32: A lane l = A[i = l & 15][k = l >> 4], B lane l = B[k = l >> 4][j = l & 15],
-// C/D lane l register r = D[i = 4 (l >> 4) + r][j = l & 15]   (NOT the f64 map: row (l >> 4) + 4 r there).
-__device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
 // ------------------------------------------------------------------------------------ Hessian
-struct Hess32Args {
-    int family;
-    const float* X;
-    int64_t ldx;
-    const double* theta;
-    const double* y;
-    const double* w;
-    const double* offset;
-    double scale;
-    int64_t N;
-    int D;
-    double* r_out;
-    double* d_out;
-    double* part;   // [gridDim.x][L] partial slabs, L = NBT*256 + NB*16
-    double* sink;   // 1024 doubles nobody reads
-};
-
-constexpr int kChunkSteps = 1024;   // k-steps a wave accumulates in f32 before folding into fp64 (multiple of 4)
-
-// A GROUP is 4 consecutive k-steps of a wave = 16 rows.  x: lane (q, c) holds X[row q of step s][16 b + c];
-// y, w, off: the per-row scalars of row (step c & 3, q) -- the row this lane LINKS (below).
-template <int NB>
-struct Grp32 {
-    float x[4][NB];
-    double y, w, off;
-};
-
-// v + (v rotated right by N lanes inside each row of 16 lanes): one v_add_f32 with a DPP operand
-template <int N>
-__device__ __forceinline__ float ror16_add_f32(float v) {
-    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, true));
-}
-
-// v of lane S of each row of 16 lanes, in every lane of that row (DPP row_newbcast: one VALU move)
-template <int S>
-__device__ __forceinline__ float bcast16(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + S, 0xf, 0xf, true));
-}
-
-// Every wave owns the WHOLE block triangle in f32 accumulators (NBT * 4 <= 144 registers) and streams its own
-// k-steps (4 rows each) straight from HBM into the MFMA operand layout -- the register-streaming design of
-// k_glm_hess_small without the split of the triangle over two waves, which fp64 needs and f32 does not.
-// WAVES = 8 (two per SIMD, 256 registers each) up to NB = 5; 4 (one per SIMD, accumulators in the AGPR half of
-// its 512 registers) above: an f32 MFMA wave with independent accumulators reaches the issue rate alone.
-//
-// VALU instructions do NOT overlap v_mfma_f32_16x16x4_f32 on gfx950 -- neither from the same wave nor from another
-// wave of the SIMD; the times add (tools/micro/mfma_f32_valu_overlap.hip: "both" = MFMA + VALU in every
-// arrangement; the instruction runs at the f32 VECTOR rate) -- so the kernel is MFMA cycles (32 each) + VALU
-// cycles (3.5 per f32 op, 5.5 .. 8 per fp64 op), and the VALU work per k-step is cut to the bone:
-//   * the row dot x_n . theta is taken in f32 against theta rounded to float (7 FMAs + 4 DPP adds per k-step; in
-//     fp64 it was 7 conversions + 7 FMAs + 12 DPP instructions at twice the cycles each).  z, and with it r and d,
-//     are therefore f32-accurate (~1e-6): inside the mode's 1e-4, and the optimiser's gradient comes from
-//     vt_glm_grad_f32, which sums in fp64;
-//   * the link (exp, reciprocal, ... ~60 fp64 instructions) is evaluated ONCE per row instead of once per lane
-//     of the row's 16-lane group: the row dots of a group's 4 k-steps leave z of row (s, q) in all 16 lanes of
-//     lane row q; lane (q, c) keeps the one of step c & 3, links it, and the MFMAs of step s fetch d_n and
-//     w_n r_n from lane (q, s) by DPP row broadcast.
-template <int NB, int FAM, bool HAS_OFF, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_glm_hess_f32(Hess32Args a) {
-    constexpr int NT = WAVES * 64;
-    constexpr int NBT = NB * (NB + 1) / 2;
-    constexpr int L = NBT * 256 + NB * 16;
-    extern __shared__ double lds[];   // fp64 slab [NBT*256] | gradient [NB*16] | theta as float [NB*16]
-    double* slab = lds;
-    double* gsum = lds + NBT * 256;
-    float* th = (float*)(lds + L);
-    for (int t = threadIdx.x; t < L; t += NT) lds[t] = 0.0;
-    for (int t = threadIdx.x; t < NB * 16; t += NT) th[t] = t < a.D ? (float)a.theta[t] : 0.f;
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int q = lane >> 4, c = lane & 15, cs = lane & 3;
-    const int clast = min(16 * (NB - 1) + c, a.D - 1);
-    const int64_t nsteps = (a.N + 3) >> 2;
-    const int64_t W = (int64_t)gridDim.x * WAVES;
-    const int64_t gw = (int64_t)blockIdx.x * WAVES + wave;
-    const int64_t per_wave = (nsteps + W - 1) / W;                      // same for every wave of the grid
-    const int64_t nchunks = (per_wave + kChunkSteps - 1) / kChunkSteps;
-
-    f32x4 acc[NBT];
-    float gacc[NB];
-
-    for (int64_t ch = 0; ch < nchunks; ++ch) {
-        const int64_t t0 = ch * kChunkSteps;
-        const int64_t t1 = min(t0 + (int64_t)kChunkSteps, per_wave);
-#pragma unroll
-        for (int i = 0; i < NBT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int b = 0; b < NB; ++b) gacc[b] = 0.f;
-
-        // The wave's t-th k-step is global k-step gw + W t.  Unconditional loads with clamped indices (see
-        // vt_hessian.hip): rows past N re-read row N-1 and get d_n = 0, columns past D re-read column D-1 and land
-        // in padding that is never stored.
-        auto load_group = [&](int64_t tg, Grp32<NB>& d) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                int64_t n = (gw + W * (tg + s)) * 4 + q;
-                n = n < a.N ? n : a.N - 1;
-                const float* xr = a.X + n * a.ldx;
-#pragma unroll
-                for (int b = 0; b < NB - 1; ++b) d.x[s][b] = xr[16 * b + c];
-                d.x[s][NB - 1] = xr[clast];
-            }
-            int64_t nl = (gw + W * (tg + cs)) * 4 + q;
-            nl = nl < a.N ? nl : a.N - 1;
-            d.y = a.y[nl];
-            d.w = a.w[nl];
-            d.off = HAS_OFF ? a.offset[nl] : 0.0;
-        };
-        struct Link { float dw, gwt; };   // of row (step c & 3, q)
-        auto link_group = [&](int64_t tg, const Grp32<NB>& d) -> Link {
-            float thv[NB];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) thv[b] = th[16 * b + c];
-            float z[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                float p = 0.f;
-#pragma unroll
-                for (int b = 0; b < NB; ++b) p = fmaf(d.x[s][b], thv[b], p);
-                p = ror16_add_f32<8>(p);
-                p = ror16_add_f32<4>(p);
-                p = ror16_add_f32<2>(p);
-                z[s] = ror16_add_f32<1>(p);
-            }
-            double zz = (double)(cs == 0 ? z[0] : (cs == 1 ? z[1] : (cs == 2 ? z[2] : z[3])));
-            const int64_t ts = tg + cs;
-            const int64_t n = (gw + W * ts) * 4 + q;
-            const bool rowok = ts < t1 && n < a.N;
-            if (HAS_OFF) zz += d.off;
-            double l1, l2;
-            if (VT_ABL32 & 2) { l1 = zz; l2 = 1.0; } else
-            vt_link(FAM, zz, d.y, l1, l2);
-            const double rr = a.scale * l1;
-            const double dw = rowok ? a.scale * d.w * l2 : 0.0;
-            // branch-free per-row outputs: lanes with nothing to store write to a sink
-            const bool st = rowok && c < 4;
-            double* rp = (st && a.r_out) ? a.r_out + n : a.sink + threadIdx.x;
-            double* dp = (st && a.d_out) ? a.d_out + n : a.sink + 512 + threadIdx.x;
-            *rp = rr;
-            *dp = dw;
-            Link lk;
-            lk.dw = (float)dw;
-            lk.gwt = rowok ? (float)(d.w * rr) : 0.f;
-            return lk;
-        };
-        auto mfma_step = [&](const float (&x)[NB], float dws, float gws) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) gacc[b] = fmaf(gws, x[b], gacc[b]);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const float bj = dws * x[j];
-#pragma unroll
-                for (int i = j; i < NB; ++i) {
-                    if (VT_ABL32 & 1) acc[vt_tri(i, j)][0] += x[i] * bj; else
-                    acc[vt_tri(i, j)] = mfma_f32(x[i], bj, acc[vt_tri(i, j)]);
-                }
-            }
-        };
-        auto mfma_group = [&](const Grp32<NB>& d, const Link& lk) {
-            mfma_step(d.x[0], bcast16<0>(lk.dw), bcast16<0>(lk.gwt));
-            mfma_step(d.x[1], bcast16<1>(lk.dw), bcast16<1>(lk.gwt));
-            mfma_step(d.x[2], bcast16<2>(lk.dw), bcast16<2>(lk.gwt));
-            mfma_step(d.x[3], bcast16<3>(lk.dw), bcast16<3>(lk.gwt));
-        };
-
-        // Ring of G groups, one group per region: region h multiplies group h, links group h+1 and refills the
-        // buffers it has just consumed with group h+G, which is linked G-1 regions later.  Two waves per SIMD
-        // cover each other's HBM latency with G = 2; a wave that has its SIMD to itself gets G = 3.
-        // k-steps past t1 that the ring touches are linked as invalid (d = 0) and contribute nothing.
-        constexpr int G = WAVES == 8 ? 2 : 3;
-        Grp32<NB> g[G];
-#pragma unroll
-        for (int i = 0; i < G; ++i) load_group(t0 + 4 * i, g[i]);
-        Link cur = link_group(t0, g[0]);
-        for (int64_t t = t0; t < t1; t += 4 * G) {
-#pragma unroll
-            for (int h = 0; h < G; ++h) {
-                mfma_group(g[h], cur);
-                cur = link_group(t + 4 * (h + 1), g[(h + 1) % G]);
-                if (!(VT_ABL32 & 4)) load_group(t + 4 * (h + G), g[h]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-
-        // ---- fold the chunk into the fp64 slab: in phase p wave w adds its blocks blk = w + p (mod WAVES), so the
-        //      waves always touch disjoint blocks; the gradient is added by one wave per phase.
-        double gv[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            double v = (double)gacc[b];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            gv[b] = v;
-        }
-        for (int p = 0; p < WAVES; ++p) {
-#pragma unroll
-            for (int blk = 0; blk < NBT; ++blk)
-                if (((blk - wave) & (WAVES - 1)) == p) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) slab[(blk * 4 + r) * 64 + lane] += (double)acc[blk][r];
-                }
-            if (p == wave && q == 0) {
-#pragma unroll
-                for (int b = 0; b < NB; ++b) gsum[16 * b + c] += gv[b];
-            }
-            __syncthreads();
-        }
-    }
-    double* out = a.part + (int64_t)blockIdx.x * L;
-    for (int e = threadIdx.x; e < L; e += NT) out[e] = lds[e];
-}
-
 // Sum the P partial slabs in a fixed order, undo the f32 accumulator layout, mirror the triangle, add the prior.
 __global__ __launch_bounds__(256) void k_hess_finalize_f32(const double* in, int L, int P, int NB, int D,
                                                            const double* prior, const double* theta, double* H,
@@ -281,31 +56,10 @@ __global__ __launch_bounds__(256) void k_hess_finalize_f32(const double* in, int
 }
 
 constexpr int hess32_waves(int NB) { return NB <= 5 ? 8 : 4; }
-inline int slab_len32(int NB) { return NB * (NB + 1) / 2 * 256 + NB * 16; }
-
-template <int NB, int FAM, bool HAS_OFF>
-int launch_hess32_3(const Hess32Args& a, int grid, hipStream_t st) {
-    static VtLdsAttr attr;   // per kernel instantiation, per device
-    const int bytes = (slab_len32(NB) + NB * 16) * (int)sizeof(double);
-    constexpr int WAVES = hess32_waves(NB);
-    if (vt_allow_big_lds((const void*)k_glm_hess_f32<NB, FAM, HAS_OFF, WAVES>, attr, 96 * 1024) != VT_OK)
-        return VT_ERR_HIP;
-    hipLaunchKernelGGL((k_glm_hess_f32<NB, FAM, HAS_OFF, WAVES>), dim3(grid), dim3(WAVES * 64), bytes, st, a);
-    return VT_OK;
-}
-
-template <int NB, int FAM>
-int launch_hess32_2(const Hess32Args& a, int grid, hipStream_t st) {
-    return a.offset ? launch_hess32_3<NB, FAM, true>(a, grid, st) : launch_hess32_3<NB, FAM, false>(a, grid, st);
-}
 
 template <int NB>
-int launch_hess32(const Hess32Args& a, int grid, hipStream_t st) {
-    switch (a.family) {
-        case VT_FAMILY_LOGISTIC: return launch_hess32_2<NB, VT_FAMILY_LOGISTIC>(a, grid, st);
-        case VT_FAMILY_POISSON: return launch_hess32_2<NB, VT_FAMILY_POISSON>(a, grid, st);
-        default: return launch_hess32_2<NB, VT_FAMILY_GAUSSIAN>(a, grid, st);
-    }
+int launch_hess32(const HessStreamArgs<float>& a, int grid, hipStream_t st) {
+    return hs_launch<float, NB, hess32_waves(NB)>(a, grid, st);
 }
 
 // ------------------------------------------------------------------------------------ TRSM
@@ -512,7 +266,7 @@ void launch_trsm32(const Trsm32Args& a, hipStream_t st) {
 extern "C" size_t vt_glm_hessian_f32_workspace_bytes(int64_t N, int D) {
     (void)N;
     if (D < 1 || D > VT_SMALL_D_MAX) return 0;
-    return ((size_t)vt_num_cu() * slab_len32((D + 15) / 16) + 1024) * sizeof(double);
+    return ((size_t)vt_num_cu() * hs_slab_len((D + 15) / 16) + 1024) * sizeof(double);
 }
 
 extern "C" int vt_glm_hessian_f32(int family, const float* X, int64_t ldx, const double* theta, const double* y,
@@ -526,14 +280,14 @@ extern "C" int vt_glm_hessian_f32(int family, const float* X, int64_t ldx, const
     if (!ws || ws_bytes < vt_glm_hessian_f32_workspace_bytes(N, D)) return VT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int NB = (D + 15) / 16;
-    const int L = slab_len32(NB);
+    const int L = hs_slab_len(NB);
     double* part = (double*)ws;
     double* sink = part + (size_t)vt_num_cu() * L;
     int grid = 0;
     if (N > 0) {
         const int64_t nsteps = (N + 3) / 4;
         grid = (int)std::max<int64_t>(1, std::min<int64_t>((nsteps + 31) / 32, vt_num_cu()));   // >= 4 k-steps per wave
-        Hess32Args a{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, sink};
+        HessStreamArgs<float> a{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, sink};
         int rc = VT_ERR_UNSUPPORTED;
         switch (NB) {
 #ifdef VT_F32_DEV_NB   // dev builds (tools/build_dev32.sh): one block count only, to keep the compile short

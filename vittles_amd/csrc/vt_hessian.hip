@@ -16,6 +16,7 @@
 // slots beside the MFMAs.  Partials are reduced deterministically (no fp64
 // atomics): 4 waves -> 1 through LDS, then a fixed-order tree over workgroups.
 #include "vt_common.h"
+#include "vt_hess_stream.h"   // k_glm_hess_stream<double, ...>: narrow designs (NB <= kStreamNB), one link per row
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -765,6 +766,10 @@ __global__ __launch_bounds__(256) void k_hess_finalize(const double* in, int L, 
 inline int num_cu() { return vt_num_cu(); }   // of the current device
 
 constexpr int kStage2 = 16;
+#ifndef VT_STREAM_NB
+#define VT_STREAM_NB 3
+#endif
+constexpr int kStreamNB = VT_STREAM_NB;   // D <= 16 kStreamNB takes k_glm_hess_stream<double> (vt_hess_stream.h)
 
 inline int slab_len(int NB) { return NB * (NB + 1) / 2 * 256 + NB * 16; }
 
@@ -864,8 +869,12 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
     }
     const int NB = (D + 15) / 16;
     const int L = slab_len(NB);
-    // dev switch, read once per process: VT_HESS_NO_TILE=1 sends every shape to the register-streaming kernel
+    // dev switches, read once per process: VT_HESS_NO_TILE=1 sends every shape to the register-streaming kernels,
+    // VT_HESS_NO_STREAM=1 sends the narrow designs to k_glm_hess_small (the round-1 kernel: every row linked 16 times)
     static const bool no_tile = getenv("VT_HESS_NO_TILE") != nullptr;
+    static const bool no_stream = getenv("VT_HESS_NO_STREAM") != nullptr;
+    static const int stream_wgs_env = getenv("VT_HESS_STREAM_WGS") ? atoi(getenv("VT_HESS_STREAM_WGS")) : 0;
+    const int stream_wgs = stream_wgs_env > 0 ? stream_wgs_env : 1;   // one 8-wave workgroup is resident per CU (registers)
     const bool tiled = N >= kTileMinRows && NB >= 4 && NB <= 8 && (ldx % 2 == 0) && ((uintptr_t)X % 16 == 0) && !no_tile;
     const int64_t ntiles = (N + tile_rows(NB) - 1) / tile_rows(NB);
     const int grid = tiled ? (int)std::min<int64_t>(ntiles, num_cu()) : hess_grid(N);
@@ -876,6 +885,23 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
 
     if (N == 0) {   // nothing to stream: the finalize kernel sums zero slabs and adds the prior
         hipLaunchKernelGGL(k_hess_finalize, dim3((L + 15) / 16), dim3(256), 0, st, (const double*)part, L, 0, NB, D,
+                           prior, theta, H, ldh, g);
+        return vt_launch_status();
+    }
+    if (NB <= kStreamNB && !no_stream) {
+        // narrow design: HBM-bound; the slabs of up to 4 workgroups per CU fit the [part | part2 | wave_part] region
+        const int64_t nsteps = (N + 3) / 4;
+        const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>((nsteps + 31) / 32,
+                                                                       (int64_t)num_cu() * std::min(std::max(stream_wgs, 1), 4)));
+        HessStreamArgs<double> sa{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, sink};
+        int rc = VT_ERR_UNSUPPORTED;
+        switch (NB) {
+            case 1: rc = hs_launch<double, 1, 8>(sa, sgrid, st); break;
+            case 2: rc = hs_launch<double, 2, 8>(sa, sgrid, st); break;
+            case 3: rc = hs_launch<double, 3, 8>(sa, sgrid, st); break;
+        }
+        if (rc != VT_OK) return rc;
+        hipLaunchKernelGGL(k_hess_finalize, dim3((L + 15) / 16), dim3(256), 0, st, (const double*)part, L, sgrid, NB, D,
                            prior, theta, H, ldh, g);
         return vt_launch_status();
     }
