@@ -281,6 +281,213 @@ __global__ __launch_bounds__(WAVES * 64) void k_glm_hess_stream(HessStreamArgs<T
 // run 1.4 .. 2.6x slower; deeper load rings, G = 3, 4, 6, do not help either: what a SIMD waits for at NB <= 2 are the
 // dependent fp64 chains of the link, ~70 instructions of ~10 cycles latency per 16 rows and wave.)
 
+// ---------------------------------------------------------------------------------------------------------------
+// D <= 32 (NB <= 2), double X: the ROW-LINK kernel.  In k_glm_hess_stream the row dot costs a DPP reduction per k-step
+// and the link's inputs sit in lane groups; for the narrowest designs that VALU work (not HBM, not the MFMA) is what
+// the pass takes.  Here a wave works on 64 rows (16 k-steps) at a time:
+//   1. its MFMA operand registers (lane (q, c) = X[row 4 s + q][16 b + c], buffer loads with SGPR base and zero-filled
+//      tail: no index clamping) are also written to a wave-private LDS tile [64 rows][16 NB + 1];
+//   2. LANE n LINKS ROW n: z = sum_j tile[n][j] theta[j] is a plain FMA chain (no cross-lane reduction), the link is
+//      evaluated once per row with all 64 lanes busy, r and d are stored as 512 contiguous bytes, and d_n, w_n r_n go
+//      to LDS;
+//   3. the 16 k-steps multiply: d_n and w_n r_n come back as LDS broadcasts, and each operand register is refilled
+//      with the next 64 rows right after its last use (a whole iteration ahead of its next one).
+// VALU instructions per 64 rows: ~180 instead of ~880; N = 4e6: D = 20 0.22 -> see DESIGN.md section 4.
+struct RowLinkLds {   // offsets in doubles
+    int slab, gsum, theta, waves, per_wave, ts, total;
+    __host__ __device__ RowLinkLds(int NB) {
+        const int NBT = NB * (NB + 1) / 2;
+        slab = 0;
+        gsum = NBT * 256;
+        theta = gsum + NB * 16;
+        waves = theta + NB * 16;
+        ts = 16 * NB + 1;                 // odd row stride: lane-per-row reads are conflict free
+        per_wave = 64 * ts + 128;         // tile | d_n [64] | w_n r_n [64]
+        total = waves + 8 * per_wave;
+    }
+};
+
+template <int NB, int NS, int FAM, bool HAS_OFF>
+__global__ __launch_bounds__(512) void k_glm_hess_rowlink(HessStreamArgs<double> a) {
+    constexpr int NT = 512, WAVES = 8;
+    constexpr int NBT = NB * (NB + 1) / 2;
+    constexpr int L = NBT * 256 + NB * 16;
+    constexpr int TS = 16 * NB + 1;
+    extern __shared__ double lds[];
+    const RowLinkLds lay(NB);
+    double* slab = lds + lay.slab;
+    double* gsum = lds + lay.gsum;
+    double* th = lds + lay.theta;
+    for (int t = threadIdx.x; t < L; t += NT) lds[t] = 0.0;
+    for (int t = threadIdx.x; t < NB * 16; t += NT) th[t] = t < a.D ? a.theta[t] : 0.0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, c = lane & 15, cs = lane & 3;
+    double* tile = lds + lay.waves + wave * lay.per_wave;
+    double* dwl = tile + 64 * TS;
+    double* gwl = dwl + 64;
+    const int64_t nsg = (a.N + 63) >> 6;                       // super-groups of 64 rows
+    const int64_t W = (int64_t)gridDim.x * WAVES;
+    const unsigned voff = (unsigned)((q * a.ldx + c) * 8);     // lane (q, c): row q of a k-step, column c of a block
+    const unsigned step_bytes = (unsigned)(4 * a.ldx * 8);     // 4 rows
+
+    // descriptor of the 64 rows of super-group sg: rows past N and everything of a super-group past the end read 0
+    auto rsrc_of = [&](int64_t sg) {
+        const int64_t r0 = sg << 6;
+        const int64_t rows = sg < nsg ? min((int64_t)64, a.N - r0) : 0;
+        const unsigned bytes = rows > 0 ? (unsigned)(((rows - 1) * a.ldx + a.D) * 8) : 0u;
+        const double* base = a.X + (rows > 0 ? r0 : 0) * a.ldx;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+    };
+    auto load_op = [&](__amdgpu_buffer_rsrc_t r, int s, int b) -> double {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff + 128u * b, step_bytes * s, 0));
+    };
+
+    f64x4 acc[NBT];
+#pragma unroll
+    for (int i = 0; i < NBT; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    double gacc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) gacc[b] = 0.0;
+
+    double xop[16][NB];
+    int64_t sg = (int64_t)blockIdx.x * WAVES + wave;
+    {
+        const __amdgpu_buffer_rsrc_t r0 = rsrc_of(sg);
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) xop[s][b] = load_op(r0, s, b);
+    }
+    // the per-row scalars of lane n's row travel one iteration ahead as well (loaded where they are used they would
+    // expose a full HBM miss per 64 rows)
+    double yn, wn, offn;
+    auto load_scalars = [&](int64_t g) {
+        const int64_t rw = (g << 6) + lane;
+        const int64_t rc = rw < a.N ? rw : a.N - 1;
+        yn = a.y[rc];
+        wn = a.w[rc];
+        offn = HAS_OFF ? a.offset[rc] : 0.0;
+    };
+    load_scalars(sg);
+    for (; sg < nsg; sg += W) {
+        const int64_t row = (sg << 6) + lane;
+        const bool ok = row < a.N;
+        const double yv = yn, wv = wn, offv = offn;
+        // 1. operand registers -> the wave's LDS tile
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) tile[(4 * s + q) * TS + 16 * b + c] = xop[s][b];
+        // 2. lane n links row n (columns past D meet theta = 0)
+        double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16 * NB; j += 2) {
+            z0 = fma(tile[lane * TS + j], th[j], z0);
+            z1 = fma(tile[lane * TS + j + 1], th[j + 1], z1);
+        }
+        double zz = z0 + z1;
+        if (HAS_OFF) zz += offv;
+        double l1, l2;
+        vt_link(FAM, zz, yv, l1, l2);
+        const double rr = a.scale * l1;
+        const double dw = ok ? a.scale * wv * l2 : 0.0;
+        double* rp = (ok && a.r_out) ? a.r_out + row : a.sink + threadIdx.x;
+        double* dp = (ok && a.d_out) ? a.d_out + row : a.sink + 512 + threadIdx.x;
+        *rp = rr;
+        *dp = dw;
+        dwl[lane] = dw;
+        gwl[lane] = ok ? wv * rr : 0.0;
+        // 3. the 16 k-steps; every operand register is refilled with the next super-group right after its last use
+        const __amdgpu_buffer_rsrc_t rn = rsrc_of(sg + W);
+        load_scalars(sg + W);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const double dws = dwl[4 * s + q], gws = gwl[4 * s + q];
+            double xs[NS > 0 ? NS : 1];
+#pragma unroll
+            for (int r = 0; r < NS; ++r) xs[r] = tile[(4 * s + q) * TS + 16 * (NB - 1) + 4 * r + cs];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) gacc[b] = fma(gws, xop[s][b], gacc[b]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const double bj = dws * xop[s][j];
+#pragma unroll
+                for (int i = j; i < NB; ++i) {
+                    if constexpr (NS > 0) {
+                        if (i == NB - 1) {
+#pragma unroll
+                            for (int r = 0; r < NS; ++r)
+                                acc[vt_tri(i, j)][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(xs[r], bj, acc[vt_tri(i, j)][r], 0, 0, 0);
+                            continue;
+                        }
+                    }
+                    acc[vt_tri(i, j)] = mfma_f64(xop[s][i], bj, acc[vt_tri(i, j)]);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) xop[s][b] = load_op(rn, s, b);
+        }
+    }
+
+    // ---- fold into the fp64 slab (fixed rotation over the waves), then one slab per workgroup
+    double gv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        double v = gacc[b];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        gv[b] = v;
+    }
+    for (int p = 0; p < WAVES; ++p) {
+#pragma unroll
+        for (int blk = 0; blk < NBT; ++blk)
+            if (((blk - wave) & (WAVES - 1)) == p) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(blk * 4 + r) * 64 + lane] += acc[blk][r];
+            }
+        if (p == wave && q == 0) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) gsum[16 * b + c] += gv[b];
+        }
+        __syncthreads();
+    }
+    double* out = a.part + (int64_t)blockIdx.x * L;
+    for (int e = threadIdx.x; e < L; e += NT) out[e] = lds[e];
+}
+
+template <int NB, int NS, int FAM, bool HAS_OFF>
+int rl_launch3(const HessStreamArgs<double>& a, int grid, hipStream_t st) {
+    static VtLdsAttr attr;   // per kernel instantiation, per device
+    const int bytes = RowLinkLds(NB).total * (int)sizeof(double);
+    if (vt_allow_big_lds((const void*)k_glm_hess_rowlink<NB, NS, FAM, HAS_OFF>, attr, 160 * 1024) != VT_OK) return VT_ERR_HIP;
+    hipLaunchKernelGGL((k_glm_hess_rowlink<NB, NS, FAM, HAS_OFF>), dim3(grid), dim3(512), bytes, st, a);
+    return VT_OK;
+}
+
+template <int NB, int NS>
+int rl_launch2(const HessStreamArgs<double>& a, int grid, hipStream_t st) {
+    const bool off = a.offset != nullptr;
+    switch (a.family) {
+        case VT_FAMILY_LOGISTIC:
+            return off ? rl_launch3<NB, NS, VT_FAMILY_LOGISTIC, true>(a, grid, st) : rl_launch3<NB, NS, VT_FAMILY_LOGISTIC, false>(a, grid, st);
+        case VT_FAMILY_POISSON:
+            return off ? rl_launch3<NB, NS, VT_FAMILY_POISSON, true>(a, grid, st) : rl_launch3<NB, NS, VT_FAMILY_POISSON, false>(a, grid, st);
+        default:
+            return off ? rl_launch3<NB, NS, VT_FAMILY_GAUSSIAN, true>(a, grid, st) : rl_launch3<NB, NS, VT_FAMILY_GAUSSIAN, false>(a, grid, st);
+    }
+}
+
+template <int NB>
+int rl_launch(const HessStreamArgs<double>& a, int grid, hipStream_t st) {
+    const int rem = a.D & 15;
+    if (rem >= 1 && rem <= 4) return rl_launch2<NB, 1>(a, grid, st);
+    if (rem >= 5 && rem <= 8) return rl_launch2<NB, 2>(a, grid, st);
+    return rl_launch2<NB, 0>(a, grid, st);
+}
+
 inline int hs_slab_len(int NB) { return NB * (NB + 1) / 2 * 256 + NB * 16; }
 
 template <typename T, int NB, int NS, int FAM, bool HAS_OFF, int WAVES>

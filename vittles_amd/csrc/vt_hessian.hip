@@ -895,6 +895,16 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
                                                                        (int64_t)num_cu() * std::min(std::max(stream_wgs, 1), 4)));
         HessStreamArgs<double> sa{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, sink};
         int rc = VT_ERR_UNSUPPORTED;
+        static const bool no_rowlink = getenv("VT_HESS_NO_ROWLINK") != nullptr;   // dev A/B switch
+        if (NB <= 2 && !no_rowlink) {
+            // 64-row super-groups, one 8-wave workgroup per CU
+            const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(((N + 63) / 64 + 7) / 8, (int64_t)num_cu()));
+            rc = NB == 1 ? rl_launch<1>(sa, rgrid, st) : rl_launch<2>(sa, rgrid, st);
+            if (rc != VT_OK) return rc;
+            hipLaunchKernelGGL(k_hess_finalize, dim3((L + 15) / 16), dim3(256), 0, st, (const double*)part, L, rgrid, NB, D,
+                               prior, theta, H, ldh, g);
+            return vt_launch_status();
+        }
         switch (NB) {
             case 1: rc = hs_launch<double, 1, 8>(sa, sgrid, st); break;
             case 2: rc = hs_launch<double, 2, 8>(sa, sgrid, st); break;
