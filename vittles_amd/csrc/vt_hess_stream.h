@@ -293,16 +293,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_glm_hess_stream(HessStreamArgs<T
 //   3. the 16 k-steps multiply: d_n and w_n r_n come back as LDS broadcasts, and each operand register is refilled
 //      with the next 64 rows right after its last use (a whole iteration ahead of its next one).
 // VALU instructions per 64 rows: ~180 instead of ~880; N = 4e6: D = 20 0.22 -> see DESIGN.md section 4.
+// NB = 3, 4 (D <= 64): the LDS tiles of 64 rows would not fit, so a wave takes RPW = 32 rows (8 k-steps) at a time and
+// lanes n and n + 32 each take half of row n's dot (one cross-lane add); both link the row, lane n stores.
 struct RowLinkLds {   // offsets in doubles
     int slab, gsum, theta, waves, per_wave, ts, total;
     __host__ __device__ RowLinkLds(int NB) {
+        const int RPW = NB <= 2 ? 64 : 32;
         const int NBT = NB * (NB + 1) / 2;
         slab = 0;
         gsum = NBT * 256;
         theta = gsum + NB * 16;
         waves = theta + NB * 16;
         ts = 16 * NB + 1;                 // odd row stride: lane-per-row reads are conflict free
-        per_wave = 64 * ts + 128;         // tile | d_n [64] | w_n r_n [64]
+        per_wave = RPW * ts + 128;        // tile | d_n [64] | w_n r_n [64]
         total = waves + 8 * per_wave;
     }
 };
@@ -313,6 +316,10 @@ __global__ __launch_bounds__(512) void k_glm_hess_rowlink(HessStreamArgs<double>
     constexpr int NBT = NB * (NB + 1) / 2;
     constexpr int L = NBT * 256 + NB * 16;
     constexpr int TS = 16 * NB + 1;
+    constexpr int RPW = NB <= 2 ? 64 : 32;     // rows per wave and iteration
+    constexpr int KS = RPW / 4;                // k-steps per iteration
+    constexpr int HALVES = 64 / RPW;           // lanes sharing a row's dot
+    constexpr int CPL = 16 * NB / HALVES;      // columns per lane in the dot
     extern __shared__ double lds[];
     const RowLinkLds lay(NB);
     double* slab = lds + lay.slab;
@@ -326,17 +333,18 @@ __global__ __launch_bounds__(512) void k_glm_hess_rowlink(HessStreamArgs<double>
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, c = lane & 15, cs = lane & 3;
     double* tile = lds + lay.waves + wave * lay.per_wave;
-    double* dwl = tile + 64 * TS;
+    double* dwl = tile + RPW * TS;
     double* gwl = dwl + 64;
-    const int64_t nsg = (a.N + 63) >> 6;                       // super-groups of 64 rows
+    const int lrow = lane & (RPW - 1), lhalf = lane / RPW;     // the row this lane links, and its part of the dot
+    const int64_t nsg = (a.N + RPW - 1) / RPW;                 // super-groups of RPW rows
     const int64_t W = (int64_t)gridDim.x * WAVES;
     const unsigned voff = (unsigned)((q * a.ldx + c) * 8);     // lane (q, c): row q of a k-step, column c of a block
     const unsigned step_bytes = (unsigned)(4 * a.ldx * 8);     // 4 rows
 
     // descriptor of the 64 rows of super-group sg: rows past N and everything of a super-group past the end read 0
     auto rsrc_of = [&](int64_t sg) {
-        const int64_t r0 = sg << 6;
-        const int64_t rows = sg < nsg ? min((int64_t)64, a.N - r0) : 0;
+        const int64_t r0 = sg * RPW;
+        const int64_t rows = sg < nsg ? min((int64_t)RPW, a.N - r0) : 0;
         const unsigned bytes = rows > 0 ? (unsigned)(((rows - 1) * a.ldx + a.D) * 8) : 0u;
         const double* base = a.X + (rows > 0 ? r0 : 0) * a.ldx;
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
@@ -352,12 +360,12 @@ __global__ __launch_bounds__(512) void k_glm_hess_rowlink(HessStreamArgs<double>
 #pragma unroll
     for (int b = 0; b < NB; ++b) gacc[b] = 0.0;
 
-    double xop[16][NB];
+    double xop[KS][NB];
     int64_t sg = (int64_t)blockIdx.x * WAVES + wave;
     {
         const __amdgpu_buffer_rsrc_t r0 = rsrc_of(sg);
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int b = 0; b < NB; ++b) xop[s][b] = load_op(r0, s, b);
     }
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(512) void k_glm_hess_rowlink(HessStreamArgs<double>
     // expose a full HBM miss per 64 rows)
     double yn, wn, offn;
     auto load_scalars = [&](int64_t g) {
-        const int64_t rw = (g << 6) + lane;
+        const int64_t rw = g * RPW + lrow;
         const int64_t rc = rw < a.N ? rw : a.N - 1;
         yn = a.y[rc];
         wn = a.w[rc];
@@ -373,38 +381,40 @@ __global__ __launch_bounds__(512) void k_glm_hess_rowlink(HessStreamArgs<double>
     };
     load_scalars(sg);
     for (; sg < nsg; sg += W) {
-        const int64_t row = (sg << 6) + lane;
+        const int64_t row = sg * RPW + lrow;
         const bool ok = row < a.N;
         const double yv = yn, wv = wn, offv = offn;
         // 1. operand registers -> the wave's LDS tile
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int b = 0; b < NB; ++b) tile[(4 * s + q) * TS + 16 * b + c] = xop[s][b];
         // 2. lane n links row n (columns past D meet theta = 0)
         double z0 = 0.0, z1 = 0.0;
 #pragma unroll
-        for (int j = 0; j < 16 * NB; j += 2) {
-            z0 = fma(tile[lane * TS + j], th[j], z0);
-            z1 = fma(tile[lane * TS + j + 1], th[j + 1], z1);
+        for (int j = 0; j < CPL; j += 2) {
+            z0 = fma(tile[lrow * TS + lhalf * CPL + j], th[lhalf * CPL + j], z0);
+            z1 = fma(tile[lrow * TS + lhalf * CPL + j + 1], th[lhalf * CPL + j + 1], z1);
         }
         double zz = z0 + z1;
+        if constexpr (HALVES == 2) zz += __shfl_xor(zz, 32, 64);
         if (HAS_OFF) zz += offv;
         double l1, l2;
         vt_link(FAM, zz, yv, l1, l2);
         const double rr = a.scale * l1;
         const double dw = ok ? a.scale * wv * l2 : 0.0;
-        double* rp = (ok && a.r_out) ? a.r_out + row : a.sink + threadIdx.x;
-        double* dp = (ok && a.d_out) ? a.d_out + row : a.sink + 512 + threadIdx.x;
+        const bool st = ok && lhalf == 0;
+        double* rp = (st && a.r_out) ? a.r_out + row : a.sink + threadIdx.x;
+        double* dp = (st && a.d_out) ? a.d_out + row : a.sink + 512 + threadIdx.x;
         *rp = rr;
         *dp = dw;
-        dwl[lane] = dw;
-        gwl[lane] = ok ? wv * rr : 0.0;
+        dwl[lrow] = dw;                    // (both halves write the same value)
+        gwl[lrow] = ok ? wv * rr : 0.0;
         // 3. the 16 k-steps; every operand register is refilled with the next super-group right after its last use
         const __amdgpu_buffer_rsrc_t rn = rsrc_of(sg + W);
         load_scalars(sg + W);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < KS; ++s) {
             const double dws = dwl[4 * s + q], gws = gwl[4 * s + q];
             double xs[NS > 0 ? NS : 1];
 #pragma unroll

@@ -767,7 +767,7 @@ inline int num_cu() { return vt_num_cu(); }   // of the current device
 
 constexpr int kStage2 = 16;
 #ifndef VT_STREAM_NB
-#define VT_STREAM_NB 3
+#define VT_STREAM_NB 4
 #endif
 constexpr int kStreamNB = VT_STREAM_NB;   // D <= 16 kStreamNB takes k_glm_hess_stream<double> (vt_hess_stream.h)
 
@@ -896,10 +896,16 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
         HessStreamArgs<double> sa{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, sink};
         int rc = VT_ERR_UNSUPPORTED;
         static const bool no_rowlink = getenv("VT_HESS_NO_ROWLINK") != nullptr;   // dev A/B switch
-        if (NB <= 2 && !no_rowlink) {
-            // 64-row super-groups, one 8-wave workgroup per CU
-            const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(((N + 63) / 64 + 7) / 8, (int64_t)num_cu()));
-            rc = NB == 1 ? rl_launch<1>(sa, rgrid, st) : rl_launch<2>(sa, rgrid, st);
+        if (!no_rowlink) {
+            // super-groups of 64 (NB <= 2) or 32 rows, one 8-wave workgroup per CU
+            const int rpw = NB <= 2 ? 64 : 32;
+            const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(((N + rpw - 1) / rpw + 7) / 8, (int64_t)num_cu()));
+            switch (NB) {
+                case 1: rc = rl_launch<1>(sa, rgrid, st); break;
+                case 2: rc = rl_launch<2>(sa, rgrid, st); break;
+                case 3: rc = rl_launch<3>(sa, rgrid, st); break;
+                case 4: rc = rl_launch<4>(sa, rgrid, st); break;
+            }
             if (rc != VT_OK) return rc;
             hipLaunchKernelGGL(k_hess_finalize, dim3((L + 15) / 16), dim3(256), 0, st, (const double*)part, L, rgrid, NB, D,
                                prior, theta, H, ldh, g);
@@ -909,6 +915,7 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
             case 1: rc = hs_launch<double, 1, 8>(sa, sgrid, st); break;
             case 2: rc = hs_launch<double, 2, 8>(sa, sgrid, st); break;
             case 3: rc = hs_launch<double, 3, 8>(sa, sgrid, st); break;
+            case 4: rc = hs_launch<double, 4, 8>(sa, sgrid, st); break;
         }
         if (rc != VT_OK) return rc;
         hipLaunchKernelGGL(k_hess_finalize, dim3((L + 15) / 16), dim3(256), 0, st, (const double*)part, L, sgrid, NB, D,
