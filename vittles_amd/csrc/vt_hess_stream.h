@@ -295,10 +295,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_glm_hess_stream(HessStreamArgs<T
 // VALU instructions per 64 rows: ~180 instead of ~880; N = 4e6: D = 20 0.22 -> see DESIGN.md section 4.
 // NB = 3, 4 (D <= 64): the LDS tiles of 64 rows would not fit, so a wave takes RPW = 32 rows (8 k-steps) at a time and
 // lanes n and n + 32 each take half of row n's dot (one cross-lane add); both link the row, lane n stores.
+// NB = 5 (D <= 80): 16 rows, four lanes per row; beyond that one wave cannot hold the whole triangle (NBT * 8
+// accumulator registers) at two waves per SIMD, which is what the tile kernel of vt_hessian.hip is for.
 struct RowLinkLds {   // offsets in doubles
     int slab, gsum, theta, waves, per_wave, ts, total;
     __host__ __device__ RowLinkLds(int NB) {
-        const int RPW = NB <= 2 ? 64 : 32;
+        const int RPW = NB <= 2 ? 64 : (NB <= 4 ? 32 : 16);
         const int NBT = NB * (NB + 1) / 2;
         slab = 0;
         gsum = NBT * 256;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(512) void k_glm_hess_rowlink(HessStreamArgs<double>
     constexpr int NBT = NB * (NB + 1) / 2;
     constexpr int L = NBT * 256 + NB * 16;
     constexpr int TS = 16 * NB + 1;
-    constexpr int RPW = NB <= 2 ? 64 : 32;     // rows per wave and iteration
+    constexpr int RPW = NB <= 2 ? 64 : (NB <= 4 ? 32 : 16);     // rows per wave and iteration
     constexpr int KS = RPW / 4;                // k-steps per iteration
     constexpr int HALVES = 64 / RPW;           // lanes sharing a row's dot
     constexpr int CPL = 16 * NB / HALVES;      // columns per lane in the dot
@@ -397,7 +399,8 @@ __global__ __launch_bounds__(512) void k_glm_hess_rowlink(HessStreamArgs<double>
             z1 = fma(tile[lrow * TS + lhalf * CPL + j + 1], th[lhalf * CPL + j + 1], z1);
         }
         double zz = z0 + z1;
-        if constexpr (HALVES == 2) zz += __shfl_xor(zz, 32, 64);
+        if constexpr (HALVES >= 2) zz += __shfl_xor(zz, 32, 64);
+        if constexpr (HALVES == 4) zz += __shfl_xor(zz, 16, 64);
         if (HAS_OFF) zz += offv;
         double l1, l2;
         vt_link(FAM, zz, yv, l1, l2);

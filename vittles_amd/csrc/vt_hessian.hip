@@ -767,7 +767,7 @@ inline int num_cu() { return vt_num_cu(); }   // of the current device
 
 constexpr int kStage2 = 16;
 #ifndef VT_STREAM_NB
-#define VT_STREAM_NB 4
+#define VT_STREAM_NB 5
 #endif
 constexpr int kStreamNB = VT_STREAM_NB;   // D <= 16 kStreamNB takes k_glm_hess_stream<double> (vt_hess_stream.h)
 
@@ -888,7 +888,8 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
                            prior, theta, H, ldh, g);
         return vt_launch_status();
     }
-    if (NB <= kStreamNB && !no_stream) {
+    static const bool no_rowlink5 = getenv("VT_HESS_NO_ROWLINK") != nullptr;
+    if (NB <= kStreamNB && !no_stream && !(NB >= 5 && no_rowlink5)) {
         // narrow design: HBM-bound; the slabs of up to 4 workgroups per CU fit the [part | part2 | wave_part] region
         const int64_t nsteps = (N + 3) / 4;
         const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>((nsteps + 31) / 32,
@@ -898,13 +899,17 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
         static const bool no_rowlink = getenv("VT_HESS_NO_ROWLINK") != nullptr;   // dev A/B switch
         if (!no_rowlink) {
             // super-groups of 64 (NB <= 2) or 32 rows, one 8-wave workgroup per CU
-            const int rpw = NB <= 2 ? 64 : 32;
+            const int rpw = NB <= 2 ? 64 : (NB <= 4 ? 32 : 16);
             const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(((N + rpw - 1) / rpw + 7) / 8, (int64_t)num_cu()));
             switch (NB) {
                 case 1: rc = rl_launch<1>(sa, rgrid, st); break;
                 case 2: rc = rl_launch<2>(sa, rgrid, st); break;
                 case 3: rc = rl_launch<3>(sa, rgrid, st); break;
                 case 4: rc = rl_launch<4>(sa, rgrid, st); break;
+                case 5: rc = rl_launch<5>(sa, rgrid, st); break;
+#if VT_STREAM_NB >= 6
+                case 6: rc = rl_launch<6>(sa, rgrid, st); break;
+#endif
             }
             if (rc != VT_OK) return rc;
             hipLaunchKernelGGL(k_hess_finalize, dim3((L + 15) / 16), dim3(256), 0, st, (const double*)part, L, rgrid, NB, D,
