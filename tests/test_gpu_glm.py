@@ -212,3 +212,25 @@ def test_empty_data_set(D, relerr):
     assert np.array_equal(rows.gemm_tn(z(0, 3), z(0, 4), bias=bias).cpu().numpy(), np.tile(np.arange(4.0), (3, 1)))
     th, info = va.optim.newton_glm(obj, w)
     assert info["converged"] and np.abs(th).max() < 1e-12          # minimiser of the prior alone
+
+
+@pytest.mark.parametrize("D", [20, 70])
+def test_fused_hessian_huge_leading_dimension(D, relerr):
+    """X as a column slice of a very wide matrix (row stride beyond the 32-bit offsets of the row-link kernel's
+    buffer descriptor): the dispatcher must take another kernel, with the same result."""
+    torch = _torch()
+    from oracle import glm
+    import vittles_amd as va
+    N, wide = 5, (1 << 22) + 64
+    rng = np.random.default_rng(D)
+    big = torch.zeros((N, wide), dtype=torch.float64, device="cuda")
+    X = rng.standard_normal((N, D))
+    big[:, 3:3 + D] = torch.tensor(X, device="cuda")
+    y = (rng.random(N) < 0.5).astype(float)
+    w = 0.5 + rng.random(N)
+    theta = rng.standard_normal(D) / np.sqrt(D)
+    obj = va.WeightedGLMObjective(big[:, 3:3 + D], y, prior=1.0)
+    assert obj.X.stride(0) == wide
+    out = obj.fused(theta, w)
+    assert relerr(out["H"].cpu().numpy(), glm.hessian("logistic", X, y, theta, w, 1.0)) < TOL
+    assert relerr(out["g"].cpu().numpy(), glm.grad("logistic", X, y, theta, w, 1.0)) < TOL

@@ -889,7 +889,7 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
         return vt_launch_status();
     }
     static const bool no_rowlink5 = getenv("VT_HESS_NO_ROWLINK") != nullptr;
-    if (NB <= kStreamNB && !no_stream && !(NB >= 5 && no_rowlink5)) {
+    if (NB <= kStreamNB && !no_stream && !(NB >= 5 && (no_rowlink5 || ldx > ((int64_t)1 << 22)))) {
         // narrow design: HBM-bound; the slabs of up to 4 workgroups per CU fit the [part | part2 | wave_part] region
         const int64_t nsteps = (N + 3) / 4;
         const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>((nsteps + 31) / 32,
@@ -897,7 +897,8 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
         HessStreamArgs<double> sa{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, sink};
         int rc = VT_ERR_UNSUPPORTED;
         static const bool no_rowlink = getenv("VT_HESS_NO_ROWLINK") != nullptr;   // dev A/B switch
-        if (!no_rowlink) {
+        // (the row-link kernel addresses 64 rows through one buffer descriptor with 32-bit offsets)
+        if (!no_rowlink && ldx <= ((int64_t)1 << 22)) {
             // super-groups of 64 (NB <= 2) or 32 rows, one 8-wave workgroup per CU
             const int rpw = NB <= 2 ? 64 : (NB <= 4 ? 32 : 16);
             const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(((N + rpw - 1) / rpw + 7) / 8, (int64_t)num_cu()));
