@@ -278,8 +278,9 @@ static int large_stages() {
 }
 
 bool lds_path_ok(const double* A, int64_t lda, const double* B, int64_t ldb, int K) {
+    // (the DMA addresses the 128 rows of a panel through one buffer descriptor with 32-bit offsets)
     return K % 2 == 0 && lda % 2 == 0 && ldb % 2 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
-           !large_no_lds();
+           lda <= ((int64_t)1 << 21) && ldb <= ((int64_t)1 << 21) && !large_no_lds();
 }
 
 int gemm_nt(double* C, int64_t ldc, int64_t M, int N, const double* A, int64_t lda, const double* B,
