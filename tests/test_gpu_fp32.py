@@ -75,13 +75,15 @@ def test_fp32_hessian_empty_and_prior_only(relerr):
     assert relerr(out["g"].cpu().numpy(), prior * theta) == 0.0
 
 
-def test_fp32_hessian_chunked_accumulation(relerr):
+@pytest.mark.parametrize("D", [90, 20, 50])
+def test_fp32_hessian_chunked_accumulation(D, relerr):
     """More than 4096 rows per wave: the f32 accumulators are folded into the fp64 slab several times
-    (one-wave-per-SIMD kernel, NB = 6: 1024 waves x 4096 rows = 4.2 M rows per fold).  Compared with the fp64
-    kernel on the same (float-representable) data; sizes beyond what the CPU oracle does in seconds."""
+    (D = 90: one-wave-per-SIMD kernel, NB = 6, 1024 waves x 4096 rows = 4.2 M rows per fold; D = 20, 50: the
+    row-link kernel, 2048 waves = 8.4 M rows per fold round).  Compared with the fp64 kernel on the same
+    (float-representable) data; sizes beyond what the CPU oracle does in seconds."""
     torch = _torch()
     import vittles_amd as va
-    N, D = 9_000_000, 90
+    N = 9_000_000
     gen = torch.Generator(device="cuda").manual_seed(5)
     X32 = torch.randn((N, D), generator=gen, device="cuda", dtype=torch.float32)
     theta = torch.randn(D, generator=gen, device="cuda", dtype=torch.float64) / D ** 0.5
@@ -95,6 +97,35 @@ def test_fp32_hessian_chunked_accumulation(relerr):
     assert relerr(d32, o64["d"][::1001].cpu().numpy()) < F32
     assert relerr(H32, o64["H"].cpu().numpy()) < F32
     assert relerr(g32, o64["g"].cpu().numpy()) < MODE   # the gradient is a sum of signed terms near an optimum-free theta
+
+
+@pytest.mark.parametrize("D", [20, 70])
+def test_fp32_hessian_huge_leading_dimension(D, relerr):
+    """X is a column block of a 4.2M-wide parent matrix: the row-link kernel's 32-bit descriptor offsets do not
+    cover that stride and the dispatch must take the 64-bit-addressed kernel."""
+    torch = _torch()
+    import vittles_amd as va
+    from vittles_amd import _lib
+    lib = _lib.load()
+    N, ld = 40, (1 << 22) + 8
+    parent = torch.zeros((N, ld), dtype=torch.float32, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    parent[:, :D] = torch.randn((N, D), generator=gen, device="cuda", dtype=torch.float32)
+    X = parent[:, :D]
+    theta = torch.randn(D, generator=gen, device="cuda", dtype=torch.float64) / D ** 0.5
+    y = (torch.rand(N, generator=gen, device="cuda", dtype=torch.float64) < 0.5).to(torch.float64)
+    w = 0.5 + torch.rand(N, generator=gen, device="cuda", dtype=torch.float64)
+    H = torch.empty((D, D), dtype=torch.float64, device="cuda")
+    g = torch.empty(D, dtype=torch.float64, device="cuda")
+    ws = torch.empty(lib.vt_glm_hessian_f32_workspace_bytes(N, D), dtype=torch.uint8, device="cuda")
+    rc = lib.vt_glm_hessian_f32(0, X.data_ptr(), X.stride(0), theta.data_ptr(), y.data_ptr(), w.data_ptr(), None, 1.0,
+                                None, N, D, H.data_ptr(), D, g.data_ptr(), None, None, ws.data_ptr(), ws.numel(),
+                                torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = va.WeightedGLMObjective(X.contiguous().to(torch.float64), y, prior=0.0).fused(theta, w)
+    assert relerr(H.cpu().numpy(), ref["H"].cpu().numpy()) < F32
+    assert relerr(g.cpu().numpy(), ref["g"].cpu().numpy()) < MODE
 
 
 def test_fp32_trsm_identity_layout():

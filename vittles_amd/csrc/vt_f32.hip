@@ -289,20 +289,37 @@ extern "C" int vt_glm_hessian_f32(int family, const float* X, int64_t ldx, const
         grid = (int)std::max<int64_t>(1, std::min<int64_t>((nsteps + 31) / 32, vt_num_cu()));   // >= 4 k-steps per wave
         HessStreamArgs<float> a{family, X, ldx, theta, y, w, offset, scale, N, D, r, d, part, sink};
         int rc = VT_ERR_UNSUPPORTED;
+        // row-link kernel (vt_hess_stream.h): 32-bit descriptor offsets, so moderate leading dimensions only
+        static const bool no_rowlink = getenv("VT_HESS_NO_ROWLINK") != nullptr;   // dev A/B switch
+        // (N = 10^6: D = 8 0.036 -> 0.026 ms, 20 0.048 -> 0.035, 64 0.082 -> 0.075; from NB = 5 on the DPP-broadcast
+        //  kernel is faster -- 0.106 against 0.115 ms at D = 80, and NB >= 7 spills here)
+        const bool rowlink = !no_rowlink && NB <= 4 && ldx <= ((int64_t)1 << 22);
+        if (rowlink) grid = rl_grid(N, NB, vt_num_cu());
+#define VT_HESS32_CASE(K)                                                                               \
+    case K:                                                                                             \
+        if constexpr (K <= 4) {                                                                         \
+            if (rowlink) {                                                                              \
+                rc = rl_launch<float, K>(a, grid, st);                                                  \
+                break;                                                                                  \
+            }                                                                                           \
+        }                                                                                               \
+        rc = launch_hess32<K>(a, grid, st);                                                             \
+        break;
         switch (NB) {
 #ifdef VT_F32_DEV_NB   // dev builds (tools/build_dev32.sh): one block count only, to keep the compile short
-            case VT_F32_DEV_NB: rc = launch_hess32<VT_F32_DEV_NB>(a, grid, st); break;
+            VT_HESS32_CASE(VT_F32_DEV_NB)
 #else
-            case 1: rc = launch_hess32<1>(a, grid, st); break;
-            case 2: rc = launch_hess32<2>(a, grid, st); break;
-            case 3: rc = launch_hess32<3>(a, grid, st); break;
-            case 4: rc = launch_hess32<4>(a, grid, st); break;
-            case 5: rc = launch_hess32<5>(a, grid, st); break;
-            case 6: rc = launch_hess32<6>(a, grid, st); break;
-            case 7: rc = launch_hess32<7>(a, grid, st); break;
-            case 8: rc = launch_hess32<8>(a, grid, st); break;
+            VT_HESS32_CASE(1)
+            VT_HESS32_CASE(2)
+            VT_HESS32_CASE(3)
+            VT_HESS32_CASE(4)
+            VT_HESS32_CASE(5)
+            VT_HESS32_CASE(6)
+            VT_HESS32_CASE(7)
+            VT_HESS32_CASE(8)
 #endif
         }
+#undef VT_HESS32_CASE
         if (rc != VT_OK) return rc;
     }
     hipLaunchKernelGGL(k_hess_finalize_f32, dim3((L + 15) / 16), dim3(256), 0, st, (const double*)part, L, grid, NB, D,

@@ -297,9 +297,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_glm_hess_stream(HessStreamArgs<T
 // lanes n and n + 32 each take half of row n's dot (one cross-lane add); both link the row, lane n stores.
 // NB = 5 (D <= 80): 16 rows, four lanes per row; beyond that one wave cannot hold the whole triangle (NBT * 8
 // accumulator registers) at two waves per SIMD, which is what the tile kernel of vt_hessian.hip is for.
-struct RowLinkLds {   // offsets in doubles
+struct RowLinkLds {   // offsets in doubles; the tiles hold T (esz = sizeof(T))
     int slab, gsum, theta, waves, per_wave, ts, total;
-    __host__ __device__ RowLinkLds(int NB) {
+    __host__ __device__ RowLinkLds(int NB, int esz) {
         const int RPW = NB <= 2 ? 64 : (NB <= 4 ? 32 : 16);
         const int NBT = NB * (NB + 1) / 2;
         slab = 0;
@@ -307,13 +307,33 @@ struct RowLinkLds {   // offsets in doubles
         theta = gsum + NB * 16;
         waves = theta + NB * 16;
         ts = 16 * NB + 1;                 // odd row stride: lane-per-row reads are conflict free
-        per_wave = RPW * ts + 128;        // tile | d_n [64] | w_n r_n [64]
+        per_wave = ((RPW * ts + 128) * esz + 7) / 8;        // tile | d_n [64] | w_n r_n [64]
         total = waves + 8 * per_wave;
     }
 };
 
-template <int NB, int NS, int FAM, bool HAS_OFF>
-__global__ __launch_bounds__(512) void k_glm_hess_rowlink(HessStreamArgs<double> a) {
+template <typename T> struct RlLoad;
+template <> struct RlLoad<double> {
+    static __device__ __forceinline__ double ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    }
+};
+template <> struct RlLoad<float> {
+    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    }
+};
+
+// T = float (fp32 storage mode, vt_f32.hip): operands, tile, row dot and the MFMA are f32, the link is fp64, and the
+// f32 accumulators are folded into the fp64 slab every HsTraits<float>::kChunk k-steps (all waves of a workgroup
+// fold together: the rounds are counted on the workgroup-uniform bound ceil(nsg / W)).  NB <= 8: the f32 triangle is
+// half the registers.
+template <typename T, int NB, int NS, int FAM, bool HAS_OFF>
+__global__ __launch_bounds__(512) void k_glm_hess_rowlink(HessStreamArgs<T> a) {
+    static_assert(NS == 0 || std::is_same<T, double>::value, "strips are fp64 only");
+    using TR = HsTraits<T>;
+    using acc_t = typename TR::acc_t;
+    constexpr int ES = (int)sizeof(T);
     constexpr int NT = 512, WAVES = 8;
     constexpr int NBT = NB * (NB + 1) / 2;
     constexpr int L = NBT * 256 + NB * 16;
@@ -322,47 +342,51 @@ __global__ __launch_bounds__(512) void k_glm_hess_rowlink(HessStreamArgs<double>
     constexpr int KS = RPW / 4;                // k-steps per iteration
     constexpr int HALVES = 64 / RPW;           // lanes sharing a row's dot
     constexpr int CPL = 16 * NB / HALVES;      // columns per lane in the dot
+        constexpr int64_t kIterChunk = TR::kChunk / KS;            // iterations between two folds
     extern __shared__ double lds[];
-    const RowLinkLds lay(NB);
+    const RowLinkLds lay(NB, ES);
     double* slab = lds + lay.slab;
     double* gsum = lds + lay.gsum;
-    double* th = lds + lay.theta;
+    T* th = (T*)(lds + lay.theta);
     for (int t = threadIdx.x; t < L; t += NT) lds[t] = 0.0;
-    for (int t = threadIdx.x; t < NB * 16; t += NT) th[t] = t < a.D ? a.theta[t] : 0.0;
+    for (int t = threadIdx.x; t < NB * 16; t += NT) th[t] = t < a.D ? (T)a.theta[t] : (T)0;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, c = lane & 15, cs = lane & 3;
-    double* tile = lds + lay.waves + wave * lay.per_wave;
-    double* dwl = tile + RPW * TS;
-    double* gwl = dwl + 64;
+    T* tile = (T*)(lds + lay.waves + wave * lay.per_wave);
+    T* dwl = tile + RPW * TS;
+    T* gwl = dwl + 64;
     const int lrow = lane & (RPW - 1), lhalf = lane / RPW;     // the row this lane links, and its part of the dot
     const int64_t nsg = (a.N + RPW - 1) / RPW;                 // super-groups of RPW rows
     const int64_t W = (int64_t)gridDim.x * WAVES;
-    const unsigned voff = (unsigned)((q * a.ldx + c) * 8);     // lane (q, c): row q of a k-step, column c of a block
-    const unsigned step_bytes = (unsigned)(4 * a.ldx * 8);     // 4 rows
+    const unsigned voff = (unsigned)((q * a.ldx + c) * ES);    // lane (q, c): row q of a k-step, column c of a block
+    const unsigned step_bytes = (unsigned)(4 * a.ldx * ES);    // 4 rows
 
-    // descriptor of the 64 rows of super-group sg: rows past N and everything of a super-group past the end read 0
+    // descriptor of the RPW rows of super-group sg: rows past N and everything of a super-group past the end read 0
     auto rsrc_of = [&](int64_t sg) {
         const int64_t r0 = sg * RPW;
         const int64_t rows = sg < nsg ? min((int64_t)RPW, a.N - r0) : 0;
-        const unsigned bytes = rows > 0 ? (unsigned)(((rows - 1) * a.ldx + a.D) * 8) : 0u;
-        const double* base = a.X + (rows > 0 ? r0 : 0) * a.ldx;
+        const unsigned bytes = rows > 0 ? (unsigned)(((rows - 1) * a.ldx + a.D) * ES) : 0u;
+        const T* base = a.X + (rows > 0 ? r0 : 0) * a.ldx;
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
     };
-    auto load_op = [&](__amdgpu_buffer_rsrc_t r, int s, int b) -> double {
-        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff + 128u * b, step_bytes * s, 0));
+    auto load_op = [&](__amdgpu_buffer_rsrc_t r, int s, int b) -> T {
+        return RlLoad<T>::ld(r, voff + (unsigned)(16 * ES) * b, step_bytes * s);
     };
 
-    f64x4 acc[NBT];
+    acc_t acc[NBT];
+    T gacc[NB];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < NBT; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    double gacc[NB];
+        for (int i = 0; i < NBT; ++i) acc[i] = (acc_t){0, 0, 0, 0};
 #pragma unroll
-    for (int b = 0; b < NB; ++b) gacc[b] = 0.0;
+        for (int b = 0; b < NB; ++b) gacc[b] = (T)0;
+    };
+    zero_acc();
 
-    double xop[KS][NB];
+    T xop[KS][NB];
     int64_t sg = (int64_t)blockIdx.x * WAVES + wave;
     {
         const __amdgpu_buffer_rsrc_t r0 = rsrc_of(sg);
@@ -382,123 +406,145 @@ __global__ __launch_bounds__(512) void k_glm_hess_rowlink(HessStreamArgs<double>
         offn = HAS_OFF ? a.offset[rc] : 0.0;
     };
     load_scalars(sg);
-    for (; sg < nsg; sg += W) {
-        const int64_t row = sg * RPW + lrow;
-        const bool ok = row < a.N;
-        const double yv = yn, wv = wn, offv = offn;
-        // 1. operand registers -> the wave's LDS tile
+    const int64_t iters_all = (nsg + W - 1) / W;               // the most iterations any wave runs (uniform)
+    for (int64_t done = 0;;) {
+        for (int64_t it = 0; it < kIterChunk && sg < nsg; ++it, sg += W) {
+            const int64_t row = sg * RPW + lrow;
+            const bool ok = row < a.N;
+            const double yv = yn, wv = wn, offv = offn;
+            // 1. operand registers -> the wave's LDS tile
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+            for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int b = 0; b < NB; ++b) tile[(4 * s + q) * TS + 16 * b + c] = xop[s][b];
-        // 2. lane n links row n (columns past D meet theta = 0)
-        double z0 = 0.0, z1 = 0.0;
+                for (int b = 0; b < NB; ++b) tile[(4 * s + q) * TS + 16 * b + c] = xop[s][b];
+            // 2. lane n links row n (columns past D meet theta = 0)
+            T z0 = 0, z1 = 0;
 #pragma unroll
-        for (int j = 0; j < CPL; j += 2) {
-            z0 = fma(tile[lrow * TS + lhalf * CPL + j], th[lhalf * CPL + j], z0);
-            z1 = fma(tile[lrow * TS + lhalf * CPL + j + 1], th[lhalf * CPL + j + 1], z1);
-        }
-        double zz = z0 + z1;
-        if constexpr (HALVES >= 2) zz += __shfl_xor(zz, 32, 64);
-        if constexpr (HALVES == 4) zz += __shfl_xor(zz, 16, 64);
-        if (HAS_OFF) zz += offv;
-        double l1, l2;
-        vt_link(FAM, zz, yv, l1, l2);
-        const double rr = a.scale * l1;
-        const double dw = ok ? a.scale * wv * l2 : 0.0;
-        const bool st = ok && lhalf == 0;
-        double* rp = (st && a.r_out) ? a.r_out + row : a.sink + threadIdx.x;
-        double* dp = (st && a.d_out) ? a.d_out + row : a.sink + 512 + threadIdx.x;
-        *rp = rr;
-        *dp = dw;
-        dwl[lrow] = dw;                    // (both halves write the same value)
-        gwl[lrow] = ok ? wv * rr : 0.0;
-        // 3. the 16 k-steps; every operand register is refilled with the next super-group right after its last use
-        const __amdgpu_buffer_rsrc_t rn = rsrc_of(sg + W);
-        load_scalars(sg + W);
+            for (int j = 0; j < CPL; j += 2) {
+                z0 = fma(tile[lrow * TS + lhalf * CPL + j], th[lhalf * CPL + j], z0);
+                z1 = fma(tile[lrow * TS + lhalf * CPL + j + 1], th[lhalf * CPL + j + 1], z1);
+            }
+            T zt = z0 + z1;
+            if constexpr (HALVES >= 2) zt += __shfl_xor(zt, 32, 64);
+            if constexpr (HALVES == 4) zt += __shfl_xor(zt, 16, 64);
+            double zz = (double)zt;
+            if (HAS_OFF) zz += offv;
+            double l1, l2;
+            vt_link(FAM, zz, yv, l1, l2);
+            const double rr = a.scale * l1;
+            const double dw = ok ? a.scale * wv * l2 : 0.0;
+            const bool st = ok && lhalf == 0;
+            double* rp = (st && a.r_out) ? a.r_out + row : a.sink + threadIdx.x;
+            double* dp = (st && a.d_out) ? a.d_out + row : a.sink + 512 + threadIdx.x;
+            *rp = rr;
+            *dp = dw;
+            dwl[lrow] = (T)dw;                 // (all lanes of a row write the same value)
+            gwl[lrow] = ok ? (T)(wv * rr) : (T)0;
+            // 3. the k-steps; every operand register is refilled with the next super-group right after its last use
+            const __amdgpu_buffer_rsrc_t rn = rsrc_of(sg + W);
+            load_scalars(sg + W);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const double dws = dwl[4 * s + q], gws = gwl[4 * s + q];
-            double xs[NS > 0 ? NS : 1];
+            for (int s = 0; s < KS; ++s) {
+                const T dws = dwl[4 * s + q], gws = gwl[4 * s + q];
+                T xs[NS > 0 ? NS : 1];
 #pragma unroll
-            for (int r = 0; r < NS; ++r) xs[r] = tile[(4 * s + q) * TS + 16 * (NB - 1) + 4 * r + cs];
+                for (int r = 0; r < NS; ++r) xs[r] = tile[(4 * s + q) * TS + 16 * (NB - 1) + 4 * r + cs];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) gacc[b] = fma(gws, xop[s][b], gacc[b]);
+                for (int b = 0; b < NB; ++b) gacc[b] = fma(gws, xop[s][b], gacc[b]);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const double bj = dws * xop[s][j];
+                for (int j = 0; j < NB; ++j) {
+                    const T bj = dws * xop[s][j];
 #pragma unroll
-                for (int i = j; i < NB; ++i) {
-                    if constexpr (NS > 0) {
-                        if (i == NB - 1) {
+                    for (int i = j; i < NB; ++i) {
+                        if constexpr (NS > 0) {
+                            if (i == NB - 1) {
 #pragma unroll
-                            for (int r = 0; r < NS; ++r)
-                                acc[vt_tri(i, j)][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(xs[r], bj, acc[vt_tri(i, j)][r], 0, 0, 0);
-                            continue;
+                                for (int r = 0; r < NS; ++r)
+                                    acc[vt_tri(i, j)][r] =
+                                        __builtin_amdgcn_mfma_f64_4x4x4f64(xs[r], bj, acc[vt_tri(i, j)][r], 0, 0, 0);
+                                continue;
+                            }
                         }
+                        acc[vt_tri(i, j)] = TR::mfma(xop[s][i], bj, acc[vt_tri(i, j)]);
                     }
-                    acc[vt_tri(i, j)] = mfma_f64(xop[s][i], bj, acc[vt_tri(i, j)]);
                 }
-            }
 #pragma unroll
-            for (int b = 0; b < NB; ++b) xop[s][b] = load_op(rn, s, b);
+                for (int b = 0; b < NB; ++b) xop[s][b] = load_op(rn, s, b);
+            }
         }
-    }
 
-    // ---- fold into the fp64 slab (fixed rotation over the waves), then one slab per workgroup
-    double gv[NB];
+        // ---- fold into the fp64 slab (fixed rotation over the waves)
+        double gv[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        double v = gacc[b];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        gv[b] = v;
-    }
-    for (int p = 0; p < WAVES; ++p) {
-#pragma unroll
-        for (int blk = 0; blk < NBT; ++blk)
-            if (((blk - wave) & (WAVES - 1)) == p) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) slab[(blk * 4 + r) * 64 + lane] += acc[blk][r];
-            }
-        if (p == wave && q == 0) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) gsum[16 * b + c] += gv[b];
+        for (int b = 0; b < NB; ++b) {
+            double v = (double)gacc[b];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            gv[b] = v;
         }
-        __syncthreads();
+        for (int p = 0; p < WAVES; ++p) {
+#pragma unroll
+            for (int blk = 0; blk < NBT; ++blk)
+                if (((blk - wave) & (WAVES - 1)) == p) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[(blk * 4 + r) * 64 + lane] += (double)acc[blk][r];
+                }
+            if (p == wave && q == 0) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) gsum[16 * b + c] += gv[b];
+            }
+            __syncthreads();
+        }
+        done += kIterChunk;
+        if (done >= iters_all) break;
+        zero_acc();
     }
+    // one slab per workgroup
     double* out = a.part + (int64_t)blockIdx.x * L;
     for (int e = threadIdx.x; e < L; e += NT) out[e] = lds[e];
 }
 
-template <int NB, int NS, int FAM, bool HAS_OFF>
-int rl_launch3(const HessStreamArgs<double>& a, int grid, hipStream_t st) {
+template <typename T, int NB, int NS, int FAM, bool HAS_OFF>
+int rl_launch3(const HessStreamArgs<T>& a, int grid, hipStream_t st) {
     static VtLdsAttr attr;   // per kernel instantiation, per device
-    const int bytes = RowLinkLds(NB).total * (int)sizeof(double);
-    if (vt_allow_big_lds((const void*)k_glm_hess_rowlink<NB, NS, FAM, HAS_OFF>, attr, 160 * 1024) != VT_OK) return VT_ERR_HIP;
-    hipLaunchKernelGGL((k_glm_hess_rowlink<NB, NS, FAM, HAS_OFF>), dim3(grid), dim3(512), bytes, st, a);
+    const int bytes = RowLinkLds(NB, (int)sizeof(T)).total * (int)sizeof(double);
+    if (vt_allow_big_lds((const void*)k_glm_hess_rowlink<T, NB, NS, FAM, HAS_OFF>, attr, 160 * 1024) != VT_OK) return VT_ERR_HIP;
+    hipLaunchKernelGGL((k_glm_hess_rowlink<T, NB, NS, FAM, HAS_OFF>), dim3(grid), dim3(512), bytes, st, a);
     return VT_OK;
 }
 
-template <int NB, int NS>
-int rl_launch2(const HessStreamArgs<double>& a, int grid, hipStream_t st) {
+template <typename T, int NB, int NS>
+int rl_launch2(const HessStreamArgs<T>& a, int grid, hipStream_t st) {
     const bool off = a.offset != nullptr;
     switch (a.family) {
         case VT_FAMILY_LOGISTIC:
-            return off ? rl_launch3<NB, NS, VT_FAMILY_LOGISTIC, true>(a, grid, st) : rl_launch3<NB, NS, VT_FAMILY_LOGISTIC, false>(a, grid, st);
+            return off ? rl_launch3<T, NB, NS, VT_FAMILY_LOGISTIC, true>(a, grid, st)
+                       : rl_launch3<T, NB, NS, VT_FAMILY_LOGISTIC, false>(a, grid, st);
         case VT_FAMILY_POISSON:
-            return off ? rl_launch3<NB, NS, VT_FAMILY_POISSON, true>(a, grid, st) : rl_launch3<NB, NS, VT_FAMILY_POISSON, false>(a, grid, st);
+            return off ? rl_launch3<T, NB, NS, VT_FAMILY_POISSON, true>(a, grid, st)
+                       : rl_launch3<T, NB, NS, VT_FAMILY_POISSON, false>(a, grid, st);
         default:
-            return off ? rl_launch3<NB, NS, VT_FAMILY_GAUSSIAN, true>(a, grid, st) : rl_launch3<NB, NS, VT_FAMILY_GAUSSIAN, false>(a, grid, st);
+            return off ? rl_launch3<T, NB, NS, VT_FAMILY_GAUSSIAN, true>(a, grid, st)
+                       : rl_launch3<T, NB, NS, VT_FAMILY_GAUSSIAN, false>(a, grid, st);
     }
 }
 
-template <int NB>
-int rl_launch(const HessStreamArgs<double>& a, int grid, hipStream_t st) {
-    const int rem = a.D & 15;
-    if (rem >= 1 && rem <= 4) return rl_launch2<NB, 1>(a, grid, st);
-    if (rem >= 5 && rem <= 8) return rl_launch2<NB, 2>(a, grid, st);
-    return rl_launch2<NB, 0>(a, grid, st);
+// strips of the last block row: D mod 16 in 1..8, double X only
+template <typename T, int NB>
+int rl_launch(const HessStreamArgs<T>& a, int grid, hipStream_t st) {
+    if constexpr (std::is_same<T, double>::value) {
+        const int rem = a.D & 15;
+        if (rem >= 1 && rem <= 4) return rl_launch2<T, NB, 1>(a, grid, st);
+        if (rem >= 5 && rem <= 8) return rl_launch2<T, NB, 2>(a, grid, st);
+    }
+    return rl_launch2<T, NB, 0>(a, grid, st);
+}
+
+// rows per wave and iteration of the row-link kernel, and its grid for N rows on cu compute units
+inline int rl_rows_per_wave(int NB) { return NB <= 2 ? 64 : (NB <= 4 ? 32 : 16); }
+inline int rl_grid(int64_t N, int NB, int cu) {
+    const int64_t nsg = (N + rl_rows_per_wave(NB) - 1) / rl_rows_per_wave(NB);
+    return (int)std::max<int64_t>(1, std::min<int64_t>((nsg + 7) / 8, cu));
 }
 
 inline int hs_slab_len(int NB) { return NB * (NB + 1) / 2 * 256 + NB * 16; }

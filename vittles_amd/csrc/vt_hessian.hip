@@ -900,16 +900,15 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
         // (the row-link kernel addresses 64 rows through one buffer descriptor with 32-bit offsets)
         if (!no_rowlink && ldx <= ((int64_t)1 << 22)) {
             // super-groups of 64 (NB <= 2) or 32 rows, one 8-wave workgroup per CU
-            const int rpw = NB <= 2 ? 64 : (NB <= 4 ? 32 : 16);
-            const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(((N + rpw - 1) / rpw + 7) / 8, (int64_t)num_cu()));
+            const int rgrid = rl_grid(N, NB, num_cu());
             switch (NB) {
-                case 1: rc = rl_launch<1>(sa, rgrid, st); break;
-                case 2: rc = rl_launch<2>(sa, rgrid, st); break;
-                case 3: rc = rl_launch<3>(sa, rgrid, st); break;
-                case 4: rc = rl_launch<4>(sa, rgrid, st); break;
-                case 5: rc = rl_launch<5>(sa, rgrid, st); break;
+                case 1: rc = rl_launch<double, 1>(sa, rgrid, st); break;
+                case 2: rc = rl_launch<double, 2>(sa, rgrid, st); break;
+                case 3: rc = rl_launch<double, 3>(sa, rgrid, st); break;
+                case 4: rc = rl_launch<double, 4>(sa, rgrid, st); break;
+                case 5: rc = rl_launch<double, 5>(sa, rgrid, st); break;
 #if VT_STREAM_NB >= 6
-                case 6: rc = rl_launch<6>(sa, rgrid, st); break;
+                case 6: rc = rl_launch<double, 6>(sa, rgrid, st); break;
 #endif
             }
             if (rc != VT_OK) return rc;
