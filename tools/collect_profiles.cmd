@@ -19,4 +19,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/blo
 timeout -k 10 120 $R/tools/micro/mfma_f64_4x4 > $O/mfma_f64_4x4.txt 2>&1 || exit 11
 timeout -k 10 120 $R/tools/micro/mfma_f32_valu_overlap > $O/mfma_f32_valu_overlap.txt 2>&1 || exit 12
 timeout -k 10 120 python3 $R/tools/time_hess32.py 100 > $O/fp32_stages.txt 2>&1 || exit 13
+timeout -k 10 200 python3 $R/tools/time_stages.py 4000000 4 8 20 32 48 64 80 > $O/narrow_d_stages.txt 2>&1 || exit 14
+for D in 8 20 64; do timeout -k 10 120 python3 $R/tools/time_hess32.py $D >> $O/fp32_stages.txt 2>&1 || exit 15; done
 echo collected

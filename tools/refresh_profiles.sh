@@ -17,6 +17,7 @@ clean gpurun_out/prof/reweight.log > profiles/${P}_reweight_stages.txt
 clean gpurun_out/prof/hvp.log > profiles/${P}_hvp_stages.txt
 clean gpurun_out/prof/block.log > profiles/${P}_block_stages.txt
 clean gpurun_out/prof/fp32_stages.txt > profiles/${P}_fp32_stages.txt
+clean gpurun_out/prof/narrow_d_stages.txt > profiles/${P}_narrow_d_stages.txt
 cp gpurun_out/prof/mfma_f64_4x4.txt profiles/${P}_mfma_f64_4x4_microbench.txt
 cp gpurun_out/prof/mfma_f32_valu_overlap.txt profiles/${P}_mfma_f32_valu_overlap.txt
 { echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 5 --warmup 2 $SIDE"
@@ -28,5 +29,5 @@ cp gpurun_out/prof/mfma_f32_valu_overlap.txt profiles/${P}_mfma_f32_valu_overlap
 { echo "# rocprofv3 --pmc SQ_* (one pass, 8 counters), python3 bench.py --steps 5 --warmup 2 $SIDE"
   python3 tools/pmc_summary.py $(newest pmc_sq counter_collection.csv) k_; } > profiles/${P}_pmc_sq_bench.txt
 { echo "# rocprofv3 --pmc SQ_* (one pass), python3 tools/time_hess32.py 100  (fp32 storage mode, N = 10^6, D = 100)"
-  python3 tools/pmc_summary.py $(newest pmc_sq32 counter_collection.csv) _f32; } > profiles/${P}_pmc_sq_fp32.txt
+  python3 tools/pmc_summary.py $(newest pmc_sq32 counter_collection.csv) k_; } > profiles/${P}_pmc_sq_fp32.txt
 python3 tools/make_traffic_json.py $(newest pmc_fetch counter_collection.csv) $(newest pmc_write counter_collection.csv) ${P} > profiles/${P}_traffic.json
