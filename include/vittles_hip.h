@@ -273,6 +273,12 @@ int    vt_gemv_f32(const float* A_dev, int64_t lda, const double* v_dev, int64_t
 int    vt_glm_value_f32(int family, const float* X_dev, int64_t ldx, const double* theta_dev,
                         const double* y_dev, const double* w_dev, const double* offset_dev, double scale,
                         int64_t N, int D, double* value_dev, void* ws_dev, size_t ws_bytes, void* stream);
+/* vt_gemm_tn with B stored in float (the fp32 mode's S): C (Da, Db) = alpha * A^T diag(s) B + 1 bias^T, A, s, the
+ * products, the sums and C in double.  Same reference lines as vt_gemm_tn (sensitivity_lib.py:245-247 in a loop);
+ * workspace from vt_gemm_tn_workspace_bytes. */
+int    vt_gemm_tn_f32b(const double* A_dev, int64_t lda, int Da, const float* B_dev, int64_t ldb, int Db,
+                       const double* rowscale_dev, int64_t N, double alpha, const double* bias_dev,
+                       double* C_dev, int64_t ldc, void* ws_dev, size_t ws_bytes, void* stream);
 
 /* ---- Synthetic inputs: counter-based generator ----------------------------------
  * Philox-4x32-10, key = seed, counter = (row, column pair, stream_id): any block of rows can be regenerated

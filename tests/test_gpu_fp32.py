@@ -245,12 +245,51 @@ def test_fp32_limits_raise_clearly():
     with pytest.raises(VittlesHipError) as e:
         obj.fused(theta, w)
     assert "fp32 mode" in str(e.value)
-    # the batched prediction and the Taylor expansion are fp64-only
+    # the Taylor expansion is fp64-only
     X, y, w, theta, _ = _problem(300, 10, "logistic", seed=2)
     obj = va.WeightedGLMObjective(X, y, prior=1.0, dtype=torch.float32)
-    sens = va.HyperparameterSensitivityLinearApproximation(obj, theta, w)
     with pytest.raises(VittlesHipError) as e:
-        sens.predict_opt_par_from_hyper_par_batch(np.stack([w, w], axis=1))
+        va.ParametricSensitivityTaylorExpansion.optimization_objective(obj, theta, w, order=2).evaluate_taylor_series(w)
     assert "fp32 storage mode" in str(e.value)
     with pytest.raises(ValueError):
         va.WeightedGLMObjective(X, y, dtype=torch.float16)
+
+
+@pytest.mark.parametrize("N,Da,Db", [(5000, 3, 20), (70000, 130, 100), (999, 64, 257), (4097, 17, 33), (1, 1, 1)])
+def test_fp32_gemm_tn_float_operand(N, Da, Db):
+    """W^T diag(s) S + bias with S stored in float: the products and sums are fp64, so the result equals the fp64
+    kernel's on the same (float-representable) values bit for bit; odd Db exercises the path without LDS-DMA."""
+    torch = _torch()
+    from vittles_amd import rows
+    gen = torch.Generator(device="cuda").manual_seed(N + Da)
+    A = torch.randn((N, Da), generator=gen, device="cuda", dtype=torch.float64)
+    B32 = torch.randn((N, Db), generator=gen, device="cuda", dtype=torch.float32)
+    s = 0.5 + torch.rand(N, generator=gen, device="cuda", dtype=torch.float64)
+    bias = torch.randn(Db, generator=gen, device="cuda", dtype=torch.float64)
+    got = rows.gemm_tn(A, B32, rowscale=s, alpha=-1.5, bias=bias)
+    want = rows.gemm_tn(A, B32.to(torch.float64), rowscale=s, alpha=-1.5, bias=bias)
+    assert got.dtype == torch.float64
+    assert torch.equal(got, want)
+
+
+def test_fp32_predict_batch_matches_loop(relerr):
+    """fp32 storage mode: the batched prediction (one W^T S product over the float S) equals the one-vector
+    prediction column by column, and the fp64 pipeline's to the mode's tolerance."""
+    torch = _torch()
+    import vittles_amd as va
+    X, y, w, theta, _ = _problem(6000, 40, "logistic", 21)
+    Xd = torch.tensor(X, device="cuda")
+    yd, wd = torch.tensor(y, device="cuda"), torch.tensor(w, device="cuda")
+    obj64 = va.WeightedGLMObjective(Xd, yd, prior=1.0)
+    theta_hat, _ = va.optim.newton_glm(obj64, wd, opt_par_init=torch.tensor(theta, device="cuda"))
+    obj32 = va.WeightedGLMObjective(Xd, yd, prior=1.0, dtype=torch.float32)
+    lin32 = va.HyperparameterSensitivityLinearApproximation(obj32, theta_hat, wd)
+    lin64 = va.HyperparameterSensitivityLinearApproximation(obj64, theta_hat, wd)
+    rng = np.random.default_rng(3)
+    W = torch.tensor(w[:, None] * rng.exponential(size=(6000, 7)), device="cuda")
+    got = lin32.predict_opt_par_from_hyper_par_batch(W)
+    assert tuple(got.shape) == (40, 7)
+    for k in range(7):
+        one = lin32.predict_opt_par_from_hyper_par(W[:, k])
+        assert relerr(got[:, k].cpu().numpy(), one.cpu().numpy()) < EXACT
+    assert relerr(got.cpu().numpy(), lin64.predict_opt_par_from_hyper_par_batch(W).cpu().numpy()) < MODE

@@ -56,6 +56,8 @@ SIGNATURES = {
     "vt_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vt_gemm_tn": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_dbl, c_ptr, c_ptr, c_i64,
                            c_ptr, c_size_t, c_ptr]),
+    "vt_gemm_tn_f32b": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_dbl, c_ptr, c_ptr, c_i64,
+                                c_ptr, c_size_t, c_ptr]),
     "vt_cg_init": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "vt_cg_update": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "vt_dot3": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),

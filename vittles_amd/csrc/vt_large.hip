@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a) {
 typedef __attribute__((address_space(3))) void* vt_ldsptr;
 constexpr int kKC = 16;                        // k per stage
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rsrc(const double* base, unsigned bytes) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ void lg_wait4_barrier() {
@@ -322,7 +322,7 @@ struct SyrkArgs {
     int ksplit;
     double* part;  // [ksplit][ntl][128*128]
     // GEN (two-operand) mode:  C = X^T diag(d) B  with B (N x Db); nt x ntb rectangular tile grid
-    const double* B;
+    const void* B;   // double, or float for the fp32 storage mode's S (k_syrk_*<true, ..., float>)
     int64_t ldb;
     int Db;
     int ntb;
@@ -341,7 +341,7 @@ __device__ __forceinline__ void tile_of(const SyrkArgs& a, int t, int& ti, int& 
     }
 }
 
-template <bool GEN>
+template <bool GEN, typename BT = double>
 __global__ __launch_bounds__(256) void k_syrk_tile(SyrkArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
@@ -379,11 +379,11 @@ __global__ __launch_bounds__(256) void k_syrk_tile(SyrkArgs a) {
             bool ok = s < s1 && n < a.N;
             int64_t nc = n < a.N ? n : a.N - 1;
             const double* xr = a.X + nc * a.ldx;
-            const double* br = GEN ? a.B + nc * a.ldb : xr;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 b.xa[i] = xr[ca[i]];
-                b.xb[i] = br[cb[i]];
+                if constexpr (GEN) b.xb[i] = (double)((const BT*)a.B + nc * a.ldb)[cb[i]];
+                else b.xb[i] = xr[cb[i]];
             }
             double dv = a.d ? a.d[nc] : 1.0;
             b.dn = ok ? dv : 0.0;
@@ -427,8 +427,11 @@ __global__ __launch_bounds__(256) void k_syrk_tile(SyrkArgs a) {
 // reads), one DMA instruction per row of a panel, d_n fetched a stage ahead.
 // STAGES = 3: one workgroup per CU, DMA two stages ahead.  STAGES = 2: 72 KB of LDS, so TWO workgroups
 // share a CU (4 waves per SIMD) and cover each other's barrier and DMA waits.
-template <bool GEN, int STAGES>
+// BT = float (GEN only): the second operand is stored in float (the fp32 storage mode's S); its panel rows are
+// 512 bytes of the same LDS slots and the B operand is converted as it is read.
+template <bool GEN, int STAGES, typename BT = double>
 __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
+    static_assert(GEN || std::is_same<BT, double>::value, "the SYRK has one (double) operand");
     extern __shared__ double lds[];            // [STAGES][I: 16 x 144 | J: 16 x 144]
     constexpr int RSTR = kT + 16, PANEL = kKC * RSTR;
     const int lane = threadIdx.x & 63;
@@ -457,9 +460,9 @@ __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
             const int n = id & 15;
             const int64_t row = r0 + (int64_t)t * kKC + n;
             const bool ok = t < nk && row < r1;
-            const double* base = (GEN && isj) ? a.B + (ok ? row : 0) * a.ldb + tj * kT
-                                              : a.X + (ok ? row : 0) * a.ldx + (isj ? tj : ti) * kT;
-            const unsigned bytes = ok ? 8u * (isj ? jcols : icols) : 0u;
+            const void* base = (GEN && isj) ? (const void*)((const BT*)a.B + (ok ? row : 0) * a.ldb + tj * kT)
+                                            : (const void*)(a.X + (ok ? row : 0) * a.ldx + (isj ? tj : ti) * kT);
+            const unsigned bytes = ok ? ((GEN && isj) ? (unsigned)sizeof(BT) : 8u) * (isj ? jcols : icols) : 0u;
             double* dst = lds + buf * (2 * PANEL) + (isj ? PANEL : 0) + n * RSTR;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(lg_rsrc(base, bytes), (vt_ldsptr)dst, 16, 16u * lane, 0, 0, 0);
         }
@@ -499,15 +502,16 @@ __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!skip) {
+            constexpr int BR = (int)(sizeof(double) / sizeof(BT));   // B elements per double of LDS
             const double* pa = lds + buf * (2 * PANEL) + q * RSTR + 64 * wm + c;
-            const double* pb = lds + buf * (2 * PANEL) + PANEL + q * RSTR + 32 * wn + c;
+            const BT* pb = (const BT*)(lds + buf * (2 * PANEL) + PANEL + q * RSTR) + 32 * wn + c;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 double af[4], bf[2];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) af[i] = pa[4 * s * RSTR + 16 * i];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = dcur[s] * pb[4 * s * RSTR + 16 * j];
+                for (int j = 0; j < 2; ++j) bf[j] = dcur[s] * (double)pb[4 * s * RSTR * BR + 16 * j];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -747,9 +751,10 @@ extern "C" size_t vt_gemm_tn_workspace_bytes(int Da, int Db) {
     return (size_t)gemm_tn_split(nta * ntb) * nta * ntb * kT * kT * sizeof(double);
 }
 
-extern "C" int vt_gemm_tn(const double* A, int64_t lda, int Da, const double* B, int64_t ldb, int Db,
-                          const double* rowscale, int64_t N, double alpha, const double* bias, double* C,
-                          int64_t ldc, void* ws, size_t ws_bytes, void* stream) {
+template <typename BT>
+static int gemm_tn_impl(const double* A, int64_t lda, int Da, const BT* B, int64_t ldb, int Db, const double* rowscale,
+                        int64_t N, double alpha, const double* bias, double* C, int64_t ldc, void* ws, size_t ws_bytes,
+                        void* stream) {
     if (!C || N < 0 || Da < 1 || Db < 1 || lda < Da || ldb < Db || ldc < Db) return VT_ERR_BAD_ARG;
     if (N > 0 && (!A || !B)) return VT_ERR_BAD_ARG;
     if (Da > VT_DENSE_D_MAX || Db > VT_DENSE_D_MAX) return VT_ERR_UNSUPPORTED;
@@ -760,20 +765,34 @@ extern "C" int vt_gemm_tn(const double* A, int64_t lda, int Da, const double* B,
     const int64_t nsteps = (N + kKC - 1) / kKC;
     if (ks > nsteps) ks = (int)std::max<int64_t>(1, nsteps);
     SyrkArgs a{A, lda, rowscale, N, Da, nta, ks, (double*)ws, B, ldb, Db, ntb};
+    constexpr int kBPer16 = 16 / (int)sizeof(BT);   // B elements per 16-byte DMA lane
     if (N == 0) {
         ks = 0;   // no rows: C = bias
-    } else if (lda % 2 == 0 && ldb % 2 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0 && !large_no_lds()) {
+    } else if (lda % 2 == 0 && ldb % kBPer16 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0 && !large_no_lds()) {
         const size_t shmem = (size_t)large_stages() * 2 * kKC * (kT + 16) * sizeof(double);   // 108 / 72 KB
         static VtLdsAttr attr[2];
-        if (vt_allow_big_lds((const void*)k_syrk_lds<true, 3>, attr[0], (int)shmem) != VT_OK ||
-            vt_allow_big_lds((const void*)k_syrk_lds<true, 2>, attr[1], (int)shmem) != VT_OK)
+        if (vt_allow_big_lds((const void*)k_syrk_lds<true, 3, BT>, attr[0], (int)shmem) != VT_OK ||
+            vt_allow_big_lds((const void*)k_syrk_lds<true, 2, BT>, attr[1], (int)shmem) != VT_OK)
             return VT_ERR_HIP;
-        if (large_stages() == 2) hipLaunchKernelGGL((k_syrk_lds<true, 2>), dim3(ntl, ks), dim3(512), shmem, st, a);
-        else hipLaunchKernelGGL((k_syrk_lds<true, 3>), dim3(ntl, ks), dim3(512), shmem, st, a);
+        if (large_stages() == 2) hipLaunchKernelGGL((k_syrk_lds<true, 2, BT>), dim3(ntl, ks), dim3(512), shmem, st, a);
+        else hipLaunchKernelGGL((k_syrk_lds<true, 3, BT>), dim3(ntl, ks), dim3(512), shmem, st, a);
     } else {
-        hipLaunchKernelGGL(k_syrk_tile<true>, dim3(ntl, ks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_syrk_tile<true, BT>), dim3(ntl, ks), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3(kT * kT / 256, ntl), dim3(256), 0, st, (const double*)ws, ntb, ntl, ks,
                        Da, Db, alpha, bias, C, ldc);
     return vt_launch_status();
+}
+
+extern "C" int vt_gemm_tn(const double* A, int64_t lda, int Da, const double* B, int64_t ldb, int Db,
+                          const double* rowscale, int64_t N, double alpha, const double* bias, double* C,
+                          int64_t ldc, void* ws, size_t ws_bytes, void* stream) {
+    return gemm_tn_impl<double>(A, lda, Da, B, ldb, Db, rowscale, N, alpha, bias, C, ldc, ws, ws_bytes, stream);
+}
+
+// fp32 storage mode: B (the sensitivity matrix S) is float; A, the sums and C stay double.
+extern "C" int vt_gemm_tn_f32b(const double* A, int64_t lda, int Da, const float* B, int64_t ldb, int Db,
+                               const double* rowscale, int64_t N, double alpha, const double* bias, double* C,
+                               int64_t ldc, void* ws, size_t ws_bytes, void* stream) {
+    return gemm_tn_impl<float>(A, lda, Da, B, ldb, Db, rowscale, N, alpha, bias, C, ldc, ws, ws_bytes, stream);
 }

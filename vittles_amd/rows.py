@@ -45,7 +45,7 @@ def _rowmajor(A):
 def _fp64_only(A, what):
     if A.dtype != torch.float64:
         raise _lib.VittlesHipError(
-            "%s is not part of the fp32 storage mode (it covers the Hessian, the sensitivity solve, gradient, HVP, "
+            "%s is not part of the fp32 storage mode (it covers the Hessian, the sensitivity solve, predictions, gradient, HVP, "
             "value, A v and A^T u): build the objective with dtype=torch.float64" % what)
 
 
@@ -125,8 +125,9 @@ def gemm_tn(A, B, rowscale=None, alpha=1.0, bias=None, out=None):
     """out (Da, Db) = alpha * A^T diag(rowscale) B + bias[None, :] for row-major CUDA tensors
     A (N, Da), B (N, Db): K9 for many weight vectors at once (fp64 MFMA, split over N)."""
     lib = dev.require_gpu()
-    _fp64_only(A, "gemm_tn")
-    _fp64_only(B, "gemm_tn (batched predictions / LR covariances)")
+    _fp64_only(A, "gemm_tn (first operand)")
+    if B.dtype not in (torch.float64, torch.float32):
+        raise TypeError("gemm_tn: B must be float64 or float32")
     A, B = _rowmajor(A), _rowmajor(B)
     N, Da = A.shape
     if B.shape[0] != N:
@@ -144,7 +145,8 @@ def gemm_tn(A, B, rowscale=None, alpha=1.0, bias=None, out=None):
         _tn_ws_cache[key] = ws
     if out is None:
         out = torch.empty((Da, Db), dtype=torch.float64, device=A.device)
-    _lib.check(lib.vt_gemm_tn(A.data_ptr(), dev.ld(A), Da, B.data_ptr(), dev.ld(B), Db, dev.ptr(rowscale),
+    fn = lib.vt_gemm_tn if B.dtype == torch.float64 else lib.vt_gemm_tn_f32b   # float B: the fp32 mode's S
+    _lib.check(fn(A.data_ptr(), dev.ld(A), Da, B.data_ptr(), dev.ld(B), Db, dev.ptr(rowscale),
                               N, float(alpha), dev.ptr(bias), out.data_ptr(), dev.ld(out), ws.data_ptr(),
                               ws.numel() * 8, dev.stream_ptr()), "vt_gemm_tn")
     return out
