@@ -569,7 +569,12 @@ template <int NB, int KL, bool LASTPERM>
 void launch_trsm(const TrsmArgs& a, hipStream_t st) {
     int64_t ngroups = (a.N + 15) / 16;
     int64_t g = (ngroups + kTrsmWaves - 1) / kTrsmWaves;
-    if (g > num_cu()) g = num_cu();
+    static const int wgs_env = getenv("VT_TRSM_WGS") ? atoi(getenv("VT_TRSM_WGS")) : 0;   // dev switch
+    // one 8-wave workgroup per CU is what the chains want; the one-block solves (D <= 16) hardly use the MFMA pipe
+    // and gain from more loads in flight (N = 4e6: D = 4 0.096 -> 0.049 ms at 4 per CU, D = 8 0.121 -> 0.103 at 2;
+    // from D = 20 on more workgroups measured 2-10 % slower)
+    const int wgs = wgs_env > 0 ? wgs_env : (NB == 1 ? (a.D <= 4 ? 4 : 2) : 1);
+    if (g > (int64_t)num_cu() * wgs) g = (int64_t)num_cu() * wgs;
     if (g < 1) g = 1;
     hipLaunchKernelGGL((k_trsm_rows_small<NB, KL, LASTPERM, kTrsmWaves>), dim3((int)g),
                        dim3(kTrsmWaves * 64), 0, st, a);
