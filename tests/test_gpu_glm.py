@@ -39,6 +39,7 @@ def test_fused_hessian_grad(N, D, family, relerr):
     prior = np.linspace(0.5, 2.0, D)
     scale = 1.5
     obj = va.WeightedGLMObjective(X, y, family=family, prior=prior, scale=scale, offset=offset)
+    assert obj.X.stride(0) % 2 == 0 and obj.X.data_ptr() % 16 == 0   # odd D: rows re-laid for the 16-byte DMA lanes
     out = obj.fused(theta, w)
     H = out["H"].cpu().numpy()
     assert relerr(H, glm.hessian(family, X, y, theta, w, prior, scale, offset)) < TOL
@@ -214,8 +215,31 @@ def test_empty_data_set(D, relerr):
     assert info["converged"] and np.abs(th).max() < 1e-12          # minimiser of the prior alone
 
 
+@pytest.mark.parametrize("N,D", [(3, 5), (257, 31), (1001, 97), (300, 113), (5003, 77), (4100, 99), (4500, 113),
+                                 (6001, 127), (4099, 65), (700, 257)])
+@pytest.mark.parametrize("family", ["logistic", "poisson", "gaussian"])
+def test_fused_hessian_grad_unaligned_rows(N, D, family, relerr, monkeypatch):
+    """Odd leading dimension kept as it is (no re-layout): the register-streaming kernels, which take any
+    8-byte aligned rows, must give the same results as the 16-byte-lane tile kernels."""
+    from oracle import glm
+    import vittles_amd as va
+    monkeypatch.setattr(va.objectives, "RELAYOUT_UNALIGNED_ROWS", False)
+    X, y, w, theta, offset = _problem(N, D, family, seed=N + D, with_offset=True)
+    obj = va.WeightedGLMObjective(X, y, family=family, prior=1.0, offset=offset)
+    assert obj.X.stride(0) == D
+    out = obj.fused(theta, w)
+    assert relerr(out["H"].cpu().numpy(), glm.hessian(family, X, y, theta, w, 1.0, 1.0, offset)) < TOL
+    assert relerr(out["g"].cpu().numpy(), glm.grad(family, X, y, theta, w, 1.0, 1.0, offset)) < TOL
+    _, l1, l2 = glm.link(family, glm.linear_predictor(X, theta, offset), y)
+    assert relerr(out["r"].cpu().numpy(), l1) < TOL
+    assert relerr(out["d"].cpu().numpy(), w * l2) < TOL
+    lin = va.HyperparameterSensitivityLinearApproximation(obj, theta, w)
+    _, _, S = glm.sensitivity(family, X, y, theta, w, 1.0, 1.0, offset)
+    assert relerr(np.asarray(lin.get_dopt_dhyper()), S) < TOL * max(1.0, np.linalg.cond(out["H"].cpu().numpy()))
+
+
 @pytest.mark.parametrize("D", [20, 70])
-def test_fused_hessian_huge_leading_dimension(D, relerr):
+def test_fused_hessian_huge_leading_dimension(D, relerr, monkeypatch):
     """X as a column slice of a very wide matrix (row stride beyond the 32-bit offsets of the row-link kernel's
     buffer descriptor): the dispatcher must take another kernel, with the same result."""
     torch = _torch()
@@ -229,6 +253,7 @@ def test_fused_hessian_huge_leading_dimension(D, relerr):
     y = (rng.random(N) < 0.5).astype(float)
     w = 0.5 + rng.random(N)
     theta = rng.standard_normal(D) / np.sqrt(D)
+    monkeypatch.setattr(va.objectives, "RELAYOUT_UNALIGNED_ROWS", False)   # keep the caller's layout
     obj = va.WeightedGLMObjective(big[:, 3:3 + D], y, prior=1.0)
     assert obj.X.stride(0) == wide
     out = obj.fused(theta, w)

@@ -23,6 +23,7 @@ for it in range(cases):
     offset = 0.1 * rng.standard_normal(N) if rng.random() < 0.4 else None
     prior = np.linspace(0.5, 2.0, D) if rng.random() < 0.7 else 1.0
     scale = float(rng.choice([1.0, 0.5, 2.5]))
+    va.objectives.RELAYOUT_UNALIGNED_ROWS = bool(rng.random() < 0.5)   # half the cases keep odd / unaligned rows as they are
     strided = rng.random() < 0.25            # X as a column slice of a wider matrix: odd / unaligned rows
     if strided:
         big = torch.tensor(np.hstack([rng.standard_normal((N, 3)), X, rng.standard_normal((N, 2))]), device="cuda")

@@ -25,6 +25,6 @@ H = out["H"]
 ms = timeit(lambda: DeviceCholesky.factor(H, check=False, pack=True))
 print("potrf+pack: %.2f ms" % ms)
 chol = DeviceCholesky.factor(H, pack=True)
-S = torch.empty((N, D), dtype=torch.float64, device="cuda")
-ms = timeit(lambda: chol.solve_rows(X, rowscale=out["r"], alpha=-1.0, out=S))
+S = chol.solve_rows(obj.X, rowscale=out["r"], alpha=-1.0)      # the library's own (16-byte pitched) layout
+ms = timeit(lambda: chol.solve_rows(obj.X, rowscale=out["r"], alpha=-1.0, out=S))
 print("trsm_rows: %.2f ms (%.1f TF)" % (ms, 2.0*N*D*D/ms/1e9))

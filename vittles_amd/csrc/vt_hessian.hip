@@ -281,7 +281,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const double* base, 
 }
 
 constexpr int kTileNQ = 4;                     // owners of the block triangle (one per SIMD)
-constexpr int kTileNM = 2;                     // MFMA waves per SIMD (3 measured the same)
+#ifndef VT_TILE_NM
+#define VT_TILE_NM 2
+#endif
+constexpr int kTileNM = VT_TILE_NM;            // MFMA waves per SIMD (3 measured the same)
 constexpr int kTileWaves = kTileNQ * (kTileNM + 1);
 constexpr int kTileThreads = 64 * kTileWaves;
 constexpr int kTileMinRows = 4096;

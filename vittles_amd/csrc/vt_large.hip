@@ -224,21 +224,35 @@ __global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
             // operand of lane (c = row, q = k) for k-step s: plane kp = 2 s + (q >> 1), element q & 1
             const double* pa = lds + buf * kGemmStage + (8 * wm + (c >> 3)) * kRB + (q >> 1) * 16 + (c & 7) * 2 + (q & 1);
             const double* pb = lds + buf * kGemmStage + PA + (4 * wn + (c >> 3)) * kRB + (q >> 1) * 16 + (c & 7) * 2 + (q & 1);
+            // odd K: the 16-byte lane that holds column K - 1 also fetched column K (inside the descriptor's range
+            // for every row but the last); the last stage then zeroes the operands of k >= K
+            auto ksteps = [&](auto masked) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                double af[4], bf[2];
+                for (int s = 0; s < 4; ++s) {
+                    double af[4], bf[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = pa[s * 32 + 2 * kRB * i];
+                    for (int i = 0; i < 4; ++i) af[i] = pa[s * 32 + 2 * kRB * i];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = pb[s * 32 + 2 * kRB * j];
+                    for (int j = 0; j < 2; ++j) bf[j] = pb[s * 32 + 2 * kRB * j];
+                    if constexpr (decltype(masked)::value) {
+                        if (t * kKC + 4 * s + q >= a.K) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                            for (int i = 0; i < 4; ++i) af[i] = 0.0;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if (VT_LABL & 2) acc[i][j][0] += af[i] * bf[j]; else
-                        acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+                            for (int j = 0; j < 2; ++j) bf[j] = 0.0;
+                        }
                     }
-            }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            if (VT_LABL & 2) acc[i][j][0] += af[i] * bf[j]; else
+                            acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+                        }
+                }
+            };
+            if ((a.K & 1) && t == nk - 1) ksteps(std::true_type{});
+            else ksteps(std::false_type{});
             buf ^= 1;
         }
         // epilogue of this tile (the next tile's first stage is in flight)
@@ -279,7 +293,8 @@ static int large_stages() {
 
 bool lds_path_ok(const double* A, int64_t lda, const double* B, int64_t ldb, int K) {
     // (the DMA addresses the 128 rows of a panel through one buffer descriptor with 32-bit offsets)
-    return K % 2 == 0 && lda % 2 == 0 && ldb % 2 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
+    (void)K;   // (odd K: the kernel masks the half-used last k pair)
+    return lda % 2 == 0 && ldb % 2 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
            lda <= ((int64_t)1 << 21) && ldb <= ((int64_t)1 << 21) && !large_no_lds();
 }
 
@@ -588,14 +603,22 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reduce(const double* part, int 
 }
 
 // ------------------------------------------------------------------ small helpers -------
-// Lc = tril(L) (ld D), LT = Lc^T
+// Lc = tril(L), LT = Lc^T, both with the even leading dimension image_ld(D) (16-byte aligned rows for the LDS-DMA
+// of the update products, whatever the parity of D); the pad column is zero.
+__host__ __device__ constexpr int image_ld(int D) { return D + (D & 1); }
 __global__ void k_copy_lower_and_transpose(const double* L, int ldl, int D, double* Lc, double* LT) {
+    const int Dl = image_ld(D);
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)D * D) return;
-    int i = (int)(idx / D), j = (int)(idx - (int64_t)i * D);
+    if (idx >= (int64_t)D * Dl) return;
+    int i = (int)(idx / Dl), j = (int)(idx - (int64_t)i * Dl);
+    if (j >= D) {   // pad column of row i of both images
+        Lc[(int64_t)i * Dl + j] = 0.0;
+        LT[(int64_t)i * Dl + j] = 0.0;
+        return;
+    }
     double v = j <= i ? L[(int64_t)i * ldl + j] : 0.0;
-    Lc[(int64_t)i * D + j] = v;
-    LT[(int64_t)j * D + i] = v;
+    Lc[(int64_t)i * Dl + j] = v;
+    LT[(int64_t)j * Dl + i] = v;
 }
 
 __global__ void k_merge_info(int* info, const int* local, int offset) {
@@ -633,20 +656,21 @@ int vt_large_potrf(double* A, int lda, int D, int* info, void* ws, hipStream_t s
 
 size_t vt_large_pack_bytes(int D) {
     const int nblk = (D + kT - 1) / kT;
-    return ((size_t)2 * D * D + (size_t)nblk * kPackStride) * sizeof(double);
+    return ((size_t)2 * D * image_ld(D) + (size_t)nblk * kPackStride) * sizeof(double);
 }
 
 int vt_large_pack(const double* L, int ldl, int D, void* pack, hipStream_t st) {
+    const int Dl = image_ld(D);
     double* Lc = (double*)pack;
-    double* LT = Lc + (size_t)D * D;
-    double* packs = LT + (size_t)D * D;
-    int64_t tot = (int64_t)D * D;
+    double* LT = Lc + (size_t)D * Dl;
+    double* packs = LT + (size_t)D * Dl;
+    int64_t tot = (int64_t)D * Dl;
     hipLaunchKernelGGL(k_copy_lower_and_transpose, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, L, ldl, D,
                        Lc, LT);
     const int nblk = (D + kT - 1) / kT;
     for (int J = 0; J < nblk; ++J) {
         const int o = J * kT, Db = std::min(kT, D - o);
-        int rc = vt_potrf_pack_block(Lc + (int64_t)o * D + o, D, Db, nullptr, packs + (size_t)J * kPackStride, 0, st);
+        int rc = vt_potrf_pack_block(Lc + (int64_t)o * Dl + o, Dl, Db, nullptr, packs + (size_t)J * kPackStride, 0, st);
         if (rc != VT_OK) return rc;
     }
     return vt_launch_status();
@@ -654,9 +678,10 @@ int vt_large_pack(const double* L, int ldl, int D, void* pack, hipStream_t st) {
 
 int vt_large_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale,
                        double alpha, int64_t N, double* Out, int64_t ldo, hipStream_t st) {
+    const int Dl = image_ld(D);
     const double* Lc = (const double*)pack;
-    const double* LT = Lc + (size_t)D * D;
-    const double* packs = LT + (size_t)D * D;
+    const double* LT = Lc + (size_t)D * Dl;
+    const double* packs = LT + (size_t)D * Dl;
     const int nblk = (D + kT - 1) / kT;
     // forward:  Y L^T = G with G = alpha * s .* B never materialised: block 0 takes it through the
     // small solve's row scale, the later blocks through the update's epilogue.
@@ -666,7 +691,7 @@ int vt_large_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, co
         if (J == 0) {
             rc = vt_trsm_rows_mode(packs, Db, B, ldb, rowscale, alpha, N, Out, ldo, 1, st);
         } else {
-            rc = gemm_nt(Out + o, ldo, N, Db, Out, ldo, Lc + (int64_t)o * D, D, o, -1.0, 0.0, false, st, B + o, ldb,
+            rc = gemm_nt(Out + o, ldo, N, Db, Out, ldo, Lc + (int64_t)o * Dl, Dl, o, -1.0, 0.0, false, st, B + o, ldb,
                          rowscale, alpha);
             if (rc != VT_OK) return rc;
             rc = vt_trsm_rows_mode(packs + (size_t)J * kPackStride, Db, Out + o, ldo, nullptr, 1.0, N, Out + o, ldo, 1, st);
@@ -677,7 +702,7 @@ int vt_large_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, co
         const int o = J * kT, Db = std::min(kT, D - o);
         const int rest = D - o - Db;
         if (rest > 0) {
-            rc = gemm_nt(Out + o, ldo, N, Db, Out + o + Db, ldo, LT + (int64_t)o * D + o + Db, D, rest, -1.0, 1.0,
+            rc = gemm_nt(Out + o, ldo, N, Db, Out + o + Db, ldo, LT + (int64_t)o * Dl + o + Db, Dl, rest, -1.0, 1.0,
                          false, st);
             if (rc != VT_OK) return rc;
         }

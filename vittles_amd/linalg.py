@@ -145,7 +145,14 @@ class DeviceCholesky:
         if B.stride(1) != 1:
             B = B.contiguous()
         if out is None:
-            out = torch.empty((N, D), dtype=B.dtype, device=B.device)
+            # rows on a 16-byte pitch: the LDS-DMA kernels that read the result later (large-D updates, W^T S) need it
+            # (sensitivity-sized results only: a handful of right-hand sides keeps the plain dense layout)
+            per16 = 16 // B.element_size()
+            Dp = (D + per16 - 1) // per16 * per16 if N >= 4096 else D
+            full = torch.empty((N, Dp), dtype=B.dtype, device=B.device)
+            if Dp > D:
+                full[:, D:] = 0
+            out = full[:, :D]
         # a single row's stride is arbitrary (torch reports 1 for a transposed (D, 1) column)
         ldb = B.stride(0) if N > 1 else D
         ldo = out.stride(0) if N > 1 else D
