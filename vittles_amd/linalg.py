@@ -148,7 +148,7 @@ class DeviceCholesky:
             # rows on a 16-byte pitch: the LDS-DMA kernels that read the result later (large-D updates, W^T S) need it
             # (sensitivity-sized results only: a handful of right-hand sides keeps the plain dense layout)
             per16 = 16 // B.element_size()
-            Dp = (D + per16 - 1) // per16 * per16 if N >= 4096 else D
+            Dp = (D + per16 - 1) // per16 * per16 if (N >= 4096 and D > 80) else D   # narrow: HBM-bound, dense rows
             full = torch.empty((N, Dp), dtype=B.dtype, device=B.device)
             if Dp > D:
                 full[:, D:] = 0
