@@ -221,38 +221,34 @@ __global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
                 if (t + 1 < nk) issue(tile, t + 1, buf ^ 1);
                 else if (next < ntiles) issue(next, 0, buf ^ 1);
             }
+            // odd K: the 16-byte lane that holds column K - 1 also fetched column K (inside the descriptor's range
+            // for every row but the last): the last stage zeroes that element of all 2 x 128 panel rows in LDS
+            // (kept out of the k-step loop: a masked copy of the loop cost 86 VGPRs and the second workgroup per CU)
+            if ((a.K & 1) && t == nk - 1) {
+                if (threadIdx.x < 2 * kT) {
+                    const int r = threadIdx.x & (kT - 1);
+                    lds[buf * kGemmStage + (threadIdx.x >= kT ? PA : 0) + (r >> 3) * kRB + (ktail >> 1) * 16 + (r & 7) * 2 + 1] = 0.0;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
             // operand of lane (c = row, q = k) for k-step s: plane kp = 2 s + (q >> 1), element q & 1
             const double* pa = lds + buf * kGemmStage + (8 * wm + (c >> 3)) * kRB + (q >> 1) * 16 + (c & 7) * 2 + (q & 1);
             const double* pb = lds + buf * kGemmStage + PA + (4 * wn + (c >> 3)) * kRB + (q >> 1) * 16 + (c & 7) * 2 + (q & 1);
-            // odd K: the 16-byte lane that holds column K - 1 also fetched column K (inside the descriptor's range
-            // for every row but the last); the last stage then zeroes the operands of k >= K
-            auto ksteps = [&](auto masked) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    double af[4], bf[2];
+            for (int s = 0; s < 4; ++s) {
+                double af[4], bf[2];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = pa[s * 32 + 2 * kRB * i];
+                for (int i = 0; i < 4; ++i) af[i] = pa[s * 32 + 2 * kRB * i];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bf[j] = pb[s * 32 + 2 * kRB * j];
-                    if constexpr (decltype(masked)::value) {
-                        if (t * kKC + 4 * s + q >= a.K) {
+                for (int j = 0; j < 2; ++j) bf[j] = pb[s * 32 + 2 * kRB * j];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) af[i] = 0.0;
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) bf[j] = 0.0;
-                        }
+                    for (int j = 0; j < 2; ++j) {
+                        if (VT_LABL & 2) acc[i][j][0] += af[i] * bf[j]; else
+                        acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
                     }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            if (VT_LABL & 2) acc[i][j][0] += af[i] * bf[j]; else
-                            acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
-                        }
-                }
-            };
-            if ((a.K & 1) && t == nk - 1) ksteps(std::true_type{});
-            else ksteps(std::false_type{});
+            }
             buf ^= 1;
         }
         // epilogue of this tile (the next tile's first stage is in flight)
