@@ -205,15 +205,38 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(const double* Ain, int
             // ---- (b) panel: row R of the blocks below:  t L_JJ^T = A[R][o..o+15]  by substitution ----
             const int R = o + 16 + tid;
             if (R < NP && !(VT_PABL & 2)) {
-                double t[16];
+                // Column-oriented, with the column of L_JJ one step ahead in registers: left to the compiler this
+                // became 16 dot products, each behind its own LDS round trip and with a dependent FMA chain as long
+                // as the row (D = 100: 45.1 -> 43.2 us for the kernel).  The reads are uniform (broadcast) and inline
+                // asm so that column m + 1 is in flight under the updates of column m.
+                typedef __attribute__((address_space(3))) void* ldsptr_t;
+                double t[16], rd[16];
 #pragma unroll
                 for (int m = 0; m < 16; ++m) t[m] = a[R * kSmallLd + o + m];
 #pragma unroll
-                for (int m = 0; m < 16; ++m) {
-                    t[m] *= rdiag_s[o + m];
+                for (int m = 0; m < 16; ++m) rd[m] = rdiag_s[o + m];
+                const unsigned lb = (unsigned)(uintptr_t)(ldsptr_t)(a + o * kSmallLd + o);   // L_JJ[0][0]
+                double Lc[2][16];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                    for (int cc = m + 1; cc < 16; ++cc) t[cc] = fma(-t[m], a[(o + cc) * kSmallLd + o + m], t[cc]);
+                for (int cc = 1; cc < 16; ++cc)
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(Lc[0][cc]) : "v"(lb), "n"(cc * kSmallLd * 8));
+#pragma unroll
+                for (int m = 0; m < 15; ++m) {
+#pragma unroll
+                    for (int cc = m + 2; cc < 16; ++cc)   // column m + 1
+                        asm volatile("ds_read_b64 %0, %1 offset:%2"
+                                     : "=v"(Lc[(m + 1) & 1][cc])
+                                     : "v"(lb), "n"((cc * kSmallLd + m + 1) * 8));
+                    // LDS returns in order: all but the 14 - m reads just issued have landed
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(14 - m) : "memory");
+#pragma unroll
+                    for (int cc = m + 1; cc < 16; ++cc) asm volatile("" : "+v"(Lc[m & 1][cc]));
+                    t[m] *= rd[m];
+#pragma unroll
+                    for (int cc = m + 1; cc < 16; ++cc) t[cc] = fma(-t[m], Lc[m & 1][cc], t[cc]);
                 }
+                t[15] *= rd[15];
 #pragma unroll
                 for (int cc = 0; cc < 16; ++cc) a[R * kSmallLd + o + cc] = t[cc];
             }
