@@ -62,6 +62,9 @@ extern "C" {
  * row-streaming entry points (link, grad, HVP, gemv, value) take D <= VT_ROWS_D_MAX.
  * Anything larger returns VT_ERR_UNSUPPORTED. */
 #define VT_SMALL_D_MAX 128
+/* VT_SMALL_D_MAX < D <= VT_MID_D_MAX: one-pass kernels with the block triangle / the solve chain dealt over the
+ * waves of a workgroup (csrc/vt_hess_mid.hip, csrc/vt_trsm_mid.hip); beyond, the 128 x 128 tiled kernels. */
+#define VT_MID_D_MAX 256
 #define VT_DENSE_D_MAX 8192
 #define VT_ROWS_D_MAX  20448
 

@@ -60,3 +60,50 @@ def test_sensitivity_large_d(N, D, family, relerr):
     assert relerr(sens.get_dopt_dhyper(), S_ref) < TOL
     w1 = w * (1.0 + 0.01 * np.cos(np.arange(N)))
     assert relerr(sens.predict_opt_par_from_hyper_par(w1), theta + S_ref @ (w1 - w)) < TOL
+
+
+# ---- mid range 129 <= D <= 256: the one-pass kernels of csrc/vt_hess_mid.hip / vt_trsm_mid.hip ----------------
+# every block count NB = 9..16, every strip count (D mod 16 in 1..4, 5..8, 9..15, 0), ragged and short tiles
+@pytest.mark.parametrize("N,D", [(1, 129), (23, 144), (24, 160), (4096, 129), (4111, 133), (5000, 137), (4099, 144),
+                                 (6001, 150), (4100, 160), (4200, 161), (4500, 176), (4800, 177), (5001, 192),
+                                 (4097, 200), (4300, 208), (4444, 215), (4600, 224), (4700, 231), (4900, 240),
+                                 (5100, 249), (8000, 255), (7777, 256)])
+@pytest.mark.parametrize("family", ["logistic", "poisson", "gaussian"])
+def test_fused_hessian_grad_mid(N, D, family, relerr):
+    from oracle import glm
+    import vittles_amd as va
+    X, y, w, _ = glm.synth(N, D, family, N + D)
+    rng = np.random.default_rng(N + D + 100)
+    w = 0.5 + rng.random(N)
+    theta = rng.standard_normal(D) / np.sqrt(D)
+    offset = 0.1 * rng.standard_normal(N) if D % 2 == 0 else None
+    prior = np.linspace(0.5, 2.0, D)
+    scale = 1.5
+    obj = va.WeightedGLMObjective(X, y, family=family, prior=prior, scale=scale, offset=offset)
+    assert obj.X.stride(0) % 2 == 0 and obj.X.data_ptr() % 16 == 0
+    out = obj.fused(theta, w)
+    H = out["H"].cpu().numpy()
+    assert relerr(H, glm.hessian(family, X, y, theta, w, prior, scale, offset)) < TOL
+    assert np.array_equal(H, H.T), "H must be exactly symmetric"
+    assert relerr(out["g"].cpu().numpy(), glm.grad(family, X, y, theta, w, prior, scale, offset)) < TOL
+    _, l1, l2 = glm.link(family, glm.linear_predictor(X, theta, offset), y)
+    assert relerr(out["r"].cpu().numpy(), scale * l1) < TOL
+    assert relerr(out["d"].cpu().numpy(), scale * w * l2) < TOL
+
+
+@pytest.mark.parametrize("N,D,family", [(4096, 129, "logistic"), (5000, 160, "poisson"), (4321, 192, "gaussian"),
+                                         (6000, 255, "logistic"), (4200, 256, "logistic"), (4100, 145, "gaussian"),
+                                         (4500, 216, "poisson")])
+def test_sensitivity_mid_d(N, D, family, relerr):
+    """D in {129, 160, 192, 255} x N >= 4096 through the drop-in class vs the oracle."""
+    from oracle import glm
+    import vittles_amd as va
+    X, y, w, _ = glm.synth(N, D, family, seed=N + D)
+    rng = np.random.default_rng(2)
+    w = 0.5 + rng.random(N)
+    theta = glm.newton_optimum(family, X, y, w, prior=1.0)
+    obj = va.WeightedGLMObjective(X, y, family=family, prior=1.0)
+    sens = va.HyperparameterSensitivityLinearApproximation(obj, theta, w, validate_optimum=True, grad_tol=1e-7)
+    H_ref, _, S_ref = glm.sensitivity(family, X, y, theta, w, prior=1.0)
+    assert relerr(sens.get_hessian_at_opt(), H_ref) < TOL
+    assert relerr(sens.get_dopt_dhyper(), S_ref) < TOL

@@ -193,6 +193,11 @@ size_t vt_large_pack_bytes(int D);
 int vt_large_pack(const double* L, int ldl, int D, void* pack, hipStream_t st);
 int vt_large_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
                        int64_t N, double* Out, int64_t ldo, hipStream_t st);
+bool vt_hess_mid_ok(const double* X, int64_t ldx, int D);
+size_t vt_hess_mid_ws_bytes(int D);
+int vt_hess_mid(int family, const double* X, int64_t ldx, const double* theta, const double* y, const double* w,
+                const double* offset, double scale, int64_t N, int D, double* r, double* d, double* part,
+                int* nslabs, hipStream_t st);
 size_t vt_large_syrk_ws_bytes(int D);
 int vt_large_syrk(const double* X, int64_t ldx, const double* d, int64_t N, int D, const double* prior, double* H,
                   int ldh, void* ws, hipStream_t st);

@@ -842,7 +842,8 @@ static size_t large_ws_rows(int D) { return (vt_rows_workspace_bytes(D) + 255) /
 extern "C" size_t vt_glm_hessian_workspace_bytes(int64_t N, int D) {
     if (D < 1) return 0;
     if (D > VT_SMALL_D_MAX)
-        return large_ws_rows(D) + (size_t)(N + D + 64) * sizeof(double) + vt_large_syrk_ws_bytes(D);
+        return std::max(large_ws_rows(D) + (size_t)(N + D + 64) * sizeof(double) + vt_large_syrk_ws_bytes(D),
+                        vt_hess_mid_ws_bytes(D));
     int NB = (D + 15) / 16;
     return ((size_t)(num_cu() + kStage2) * slab_len(NB) + (size_t)num_cu() * 4 * (NB * (NB + 1) / 2) * 256 + 1024) *
            sizeof(double);
@@ -858,6 +859,17 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
     if (family < 0 || family > 2) return VT_ERR_BAD_ARG;
     if (!ws || ws_bytes < vt_glm_hessian_workspace_bytes(N, D)) return VT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (N > 0 && vt_hess_mid_ok(X, ldx, D)) {
+        // 129 <= D <= 256: one fused pass (vt_hess_mid.hip), slabs summed by the same finalize launch
+        const int NBm = (D + 15) / 16;
+        int nslabs = 0;
+        int rc = vt_hess_mid(family, X, ldx, theta, y, w, offset, scale, N, D, r, d, (double*)ws, &nslabs, st);
+        if (rc != VT_OK) return rc;
+        const int Lm = slab_len(NBm);
+        hipLaunchKernelGGL(k_hess_finalize, dim3((Lm + 15) / 16), dim3(256), 0, st, (const double*)ws, Lm, nslabs, NBm, D,
+                           prior, theta, H, ldh, g);
+        return vt_launch_status();
+    }
     if (D > VT_SMALL_D_MAX) {
         char* base = (char*)ws;
         double* dtmp = (double*)(base + large_ws_rows(D));
