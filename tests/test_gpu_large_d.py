@@ -107,3 +107,29 @@ def test_sensitivity_mid_d(N, D, family, relerr):
     H_ref, _, S_ref = glm.sensitivity(family, X, y, theta, w, prior=1.0)
     assert relerr(sens.get_hessian_at_opt(), H_ref) < TOL
     assert relerr(sens.get_dopt_dhyper(), S_ref) < TOL
+
+
+# the chain kernels of csrc/vt_trsm_mid.h directly: every block count NB = 9..16 with every last-block class
+# (1..4, 5..8, 9..15, 16 columns), one / ragged / many tiles, odd row pitches, in place
+@pytest.mark.parametrize("D", [129, 133, 137, 144, 145, 150, 158, 160, 161, 166, 171, 176, 178, 185, 190, 192, 193,
+                               200, 207, 208, 212, 216, 223, 224, 228, 231, 239, 240, 241, 247, 255, 256])
+def test_trsm_rows_mid(D, relerr):
+    import torch
+    from vittles_amd.linalg import DeviceCholesky
+    rng = np.random.default_rng(D)
+    A = rng.standard_normal((2 * D, D))
+    H = A.T @ A / D + np.eye(D)
+    cf = scipy.linalg.cho_factor(H)
+    chol = DeviceCholesky.factor(torch.tensor(H, device="cuda"), pack=True)
+    for N, pad in [(1, 0), (17, 1), (4096 + D, 0), (40000 + D, 3)]:
+        B = rng.standard_normal((N, D + pad))
+        s = 0.5 + rng.random(N)
+        Bd = torch.tensor(B, device="cuda")[:, :D]
+        out = torch.full((N, D + pad), -7.0, dtype=torch.float64, device="cuda")
+        got = chol.solve_rows(Bd, rowscale=torch.tensor(s, device="cuda"), alpha=-1.5, out=out[:, :D])
+        ref = -1.5 * s[:, None] * scipy.linalg.cho_solve(cf, B[:, :D].T).T
+        assert relerr(got.cpu().numpy(), ref) < 1e-9
+        assert torch.all(out[:, D:] == -7.0), "columns past D must not be written"
+        Bi = Bd.clone() if pad == 0 else Bd
+        chol.solve_rows(Bi, out=Bi)     # in place, no row scale
+        assert relerr(Bi.cpu().numpy(), scipy.linalg.cho_solve(cf, B[:, :D].T).T) < 1e-9

@@ -3,6 +3,7 @@
 // (vittles/solver_lib.py:26-29) and the N-right-hand-side solve behind
 // `-1 * self._hess_solver(jac0)` (vittles/sensitivity_lib.py:226).
 #include "vt_common.h"
+#include "vt_trsm_sched.h"
 #ifndef VT_PABL
 #define VT_PABL 0   // dev-only compile-time ablation mask
 #endif
@@ -27,10 +28,6 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
-}
-
-__host__ __device__ __forceinline__ int vt_perm(bool permuted, int p) {
-    return permuted ? (4 * (p & 3) + (p >> 2)) : p;
 }
 
 // do_factor: factor the matrix at Ain (leading dimension ldin) into A (Ain == A: in place; otherwise A
@@ -359,56 +356,6 @@ struct TrsmArgs {
 // operands are read from LDS while product k's MFMAs run, and sched_barriers keep
 // hipcc from hoisting all ~200 ds_reads to the top (which spills hundreds of VGPRs).
 template <int NB, int KL, bool LASTPERM>
-struct TrsmSched {
-    static constexpr int NBT = NB * (NB + 1) / 2;
-    static constexpr int M = 2 * NBT;
-    static constexpr bool permuted(int b) { return b < NB - 1 || LASTPERM; }
-    static constexpr int ks(int b) { return permuted(b) ? 4 : KL; }
-    // product idx -> (backward?, row block j, source block i)
-    static constexpr bool bwd(int idx) { return idx >= NBT; }
-    static constexpr int row(int idx) {
-        if (idx < NBT) {  // forward: j = 0..NB-1, i = j..0
-            int j = 0, k = idx;
-            while (k > j) { k -= j + 1; ++j; }
-            return j;
-        }
-        int k = idx - NBT, j = NB - 1;  // backward: j = NB-1..0, i = j..NB-1
-        while (k >= NB - j) { k -= NB - j; --j; }
-        return j;
-    }
-    static constexpr int src(int idx) {
-        if (idx < NBT) {
-            int j = 0, k = idx;
-            while (k > j) { k -= j + 1; ++j; }
-            return j - k;
-        }
-        int k = idx - NBT, j = NB - 1;
-        while (k >= NB - j) { k -= NB - j; --j; }
-        return j + k;
-    }
-    static constexpr bool first(int idx) { return src(idx) == row(idx); }
-    static constexpr bool last(int idx) { return bwd(idx) ? src(idx) == NB - 1 : src(idx) == 0; }
-    // index of the pack image for this product
-    static constexpr int image(int idx) {
-        return bwd(idx) ? NBT + vt_tri(src(idx), row(idx)) : vt_tri(row(idx), src(idx));
-    }
-};
-
-// Row strips of the LAST block row.  When the trailing partial block has KL <= 2 k-steps (D mod 16 in 1..8) only
-// the first 4 KL parameter rows of block row NB-1 exist, and its products are computed by KL
-// v_mfma_f64_4x4x4_4b per k-step (16 pipe cycles each) instead of one 64-cycle 16x16x4 product: the four 4x4
-// blocks of that instruction take the SAME 4 rows of the A image (lane l reads the image at lane
-// (l & 48) | (4 r + (l & 3))) against the four 4-column groups of the ordinary B operand, and result lane L holds
-// row 4 r + (L >> 4), right-hand side L & 15: exactly register r of the 16x16 accumulator (see vt_hessian.hip).
-// D = 100: 26 of the 200 products of a tile shrink from 64 to 16 cycles (-9.75 % of the MFMA pipe time).
-template <int NB, int KL, bool LASTPERM>
-struct TrsmSched2 : TrsmSched<NB, KL, LASTPERM> {
-    static constexpr int STRIPS = (!LASTPERM && KL <= 2) ? KL : 0;
-    static constexpr bool strip_row(int idx) { return STRIPS > 0 && TrsmSched<NB, KL, LASTPERM>::row(idx) == NB - 1; }
-    static constexpr int NSET = STRIPS > 1 ? STRIPS : 1;     // A-operand sets per k-step
-};
-
-template <int NB, int KL, bool LASTPERM>
 struct TrsmState {
     static constexpr int NSET = TrsmSched2<NB, KL, LASTPERM>::NSET;
     f64x4 V[NB];
@@ -678,6 +625,7 @@ extern "C" int vt_potrs(const double* L, int ldl, int D, double* B, int64_t ldb_
 
 extern "C" size_t vt_trsm_pack_bytes(int D) {
     if (D < 1 || D > kLargeDMax) return 0;
+    if (vt_mid_trsm_ok(D)) return std::max(vt_mid_pack_bytes(D), vt_large_pack_bytes(D));
     if (D > VT_SMALL_D_MAX) return vt_large_pack_bytes(D);
     int NB = (D + 15) / 16;
     return (size_t)2 * (NB * (NB + 1) / 2) * 256 * sizeof(double);
@@ -686,6 +634,7 @@ extern "C" size_t vt_trsm_pack_bytes(int D) {
 extern "C" int vt_trsm_pack(const double* L, int ldl, int D, void* pack, void* stream) {
     if (!L || !pack || D < 1 || ldl < D) return VT_ERR_BAD_ARG;
     if (D > kLargeDMax) return VT_ERR_UNSUPPORTED;
+    if (vt_mid_trsm_ok(D)) return vt_mid_pack(L, ldl, D, pack, (hipStream_t)stream);
     if (D > VT_SMALL_D_MAX) return vt_large_pack(L, ldl, D, pack, (hipStream_t)stream);
     return vt_potrf_pack_block((double*)L, ldl, D, nullptr, (double*)pack, 0, (hipStream_t)stream);
 }
@@ -694,10 +643,11 @@ extern "C" int vt_potrf_pack(double* A, int lda, int D, int* info, void* pack, v
     if (!A || !info || !pack || D < 1 || lda < D) return VT_ERR_BAD_ARG;
     if (D > kLargeDMax) return VT_ERR_UNSUPPORTED;
     if (D > VT_SMALL_D_MAX) {
-        // the L / L^T images of the pack (2 D^2 doubles) are free until vt_large_pack fills them:
-        // they serve as the factorisation's scratch.
+        // the L / L^T images of the pack (2 D^2 doubles; the chain images of a mid-range pack) are free until the
+        // pack kernels fill them: they serve as the factorisation's scratch.
         int rc = vt_large_potrf(A, lda, D, info, pack, (hipStream_t)stream);
         if (rc != VT_OK) return rc;
+        if (vt_mid_trsm_ok(D)) return vt_mid_pack(A, lda, D, pack, (hipStream_t)stream);
         return vt_large_pack(A, lda, D, pack, (hipStream_t)stream);
     }
     return vt_potrf_pack_block(A, lda, D, info, (double*)pack, 1, (hipStream_t)stream);
@@ -724,6 +674,7 @@ extern "C" int vt_trsm_rows(const void* pack, int D, const double* B, int64_t ld
     if (D > kLargeDMax) return VT_ERR_UNSUPPORTED;
     if (N == 0) return VT_OK;
     if (!B || !Out) return VT_ERR_BAD_ARG;
+    if (vt_mid_trsm_ok(D)) return vt_mid_trsm_rows(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, (hipStream_t)stream);
     if (D > VT_SMALL_D_MAX)
         return vt_large_trsm_rows(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, (hipStream_t)stream);
     return vt_trsm_rows_mode(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, 0, (hipStream_t)stream);

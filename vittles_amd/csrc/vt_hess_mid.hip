@@ -15,11 +15,14 @@
 //     slab in the workspace (no reduction through LDS).
 //   * X goes HBM -> LDS by buffer_load ... lds (rows zero-filled past D by the descriptor's range check),
 //     two periods ahead, three tile buffers in rotation, exactly as in the tile kernel; y, w, offset ride along.
-//   * there is no room for service waves (12 waves per CU would cap every wave at 168 registers), so the two
-//     waves of a SIMD have two roles: wave A issues the SIMD's share of the DMA, wave B LINKS the SIMD's rows of
-//     the next tile (row dot by DPP, the exp / rcp chain once per row on one lane per row, gradient, r_n and
-//     d_n out) before its MFMAs of the period.  While B links, A issues MFMAs alone (one wave alone gets about
-//     half the pipe), so B owns VT_MID_LINK_DELTA pipe cycles per k-step less than A.
+//   * the LINK of the next tile (row dot by DPP, the exp / rcp chain once per row on one lane per row, gradient,
+//     r_n and d_n out) is a long dependent VALU chain whose every instruction queues behind the fp64 MFMAs of the
+//     SIMD.  SVC = true (NB <= kMidSvcNB: the owners fit 168 registers): 12 waves per CU, the third wave of every
+//     SIMD is a SERVICE wave that only links (as in the tile kernel), so the chain's latency is off the MFMA waves'
+//     path.  SVC = false (more accumulators per owner than three waves per SIMD leave room for): the two waves
+//     of a SIMD have two roles, wave A issues the SIMD's share of the DMA, wave B links before its MFMAs of the
+//     period and owns VT_MID_LINK_DELTA pipe cycles per k-step less than A (measured at N = 2e6: the link costs
+//     about 1.8 us per period this way, D = 129 1.12 ms against 0.79 ms at D = 128).
 //   * the last block row is computed with 4x4x4 MFMA strips when D mod 16 <= 8 (as in the tile kernel), so
 //     D = 129 costs 8 full block rows + one 4-row strip, not 9 block rows.
 #include "vt_common.h"
@@ -29,7 +32,7 @@
 #define VT_MID_LINK_DELTA 80
 #endif
 #ifndef VT_MABL
-#define VT_MABL 0   // dev-only ablation mask: 1 no MFMA, 2 no DMA after the prologue, 4 no link
+#define VT_MABL 0   // dev-only compile-time ablation mask: 1 no MFMA, 2 no DMA, 4 no link
 #endif
 
 namespace {
@@ -72,12 +75,12 @@ struct MidTab {
     bool strip[8];                  // owns a block of the strip row
     int nown[8];
 };
-__host__ __device__ constexpr MidTab make_mid_tab(int NB, int NS) {
+__host__ __device__ constexpr MidTab make_mid_tab(int NB, int NS, int delta_in) {
     MidTab t{};
     int total = 0;
     for (int j = 0; j < NB; ++j)
         for (int i = j; i < NB; ++i) total += mid_cost(NB, NS, i);
-    int delta = VT_MID_LINK_DELTA;
+    int delta = delta_in;
     if (4 * delta > total / 2) delta = total / 8;
     int thr[8] = {};   // cumulative targets, in units of 1/8 pipe cycle
     int cum = 0;
@@ -126,89 +129,57 @@ struct MidLds {   // offsets in doubles
     static constexpr int kTotal = kOff + 3 * TR;
 };
 
-template <int NB, int NS, int O>
-__device__ __forceinline__ void mid_wave(const MidArgs& a, double* lds, int64_t mine) {
-    using LY = MidLds<NB>;
-    constexpr int RS = LY::RS, TR = LY::TR;
-    constexpr int NBT = NB * (NB + 1) / 2;
-    constexpr int TYPE = O >> 2, SIMD = O & 3;
-    constexpr int KSTEPS = TR / 4;
-    constexpr int RPS = TR / 4;                        // rows of a tile per SIMD (DMA share, link share)
-    constexpr int PASSES = (RPS + 3) / 4;
-    constexpr int CH = RS / 2;                         // 16-byte chunks per LDS row
-    constexpr int DMAH = (CH + 63) / 64;               // DMA instructions per row
-    constexpr MidTab TAB = make_mid_tab(NB, NS);
-    constexpr unsigned long long W0 = TAB.own[O][0], W1 = TAB.own[O][1], W2 = TAB.own[O][2];
-    constexpr unsigned NEED = TAB.rows[O] | TAB.cols[O], COLS = TAB.cols[O];
-    constexpr bool STRIP = TAB.strip[O];
-    constexpr int NOWN = TAB.nown[O];
-    static_assert(2 * RPS <= 64, "one DMA instruction moves a SIMD's per-row scalars");
-
-    const int lane = threadIdx.x & 63;
-    const int q = lane >> 4, c = lane & 15;
-    const int64_t ntile_rows = TR;
-    auto first_row = [&](int64_t k) -> int64_t { return (blockIdx.x + k * (int64_t)gridDim.x) * ntile_rows; };
-    auto nrow_of = [&](int64_t k) -> int {
+// Which rows of X a workgroup's k-th tile holds (tiles are dealt round-robin over the grid).
+template <int TR>
+struct MidRows {
+    const MidArgs& a;
+    int64_t mine;
+    __device__ __forceinline__ int64_t first_row(int64_t k) const { return (blockIdx.x + k * (int64_t)gridDim.x) * (int64_t)TR; }
+    __device__ __forceinline__ int nrow(int64_t k) const {
         const int64_t left = (k >= 0 && k < mine) ? a.N - first_row(k) : 0;
         return (int)(left < TR ? (left > 0 ? left : 0) : TR);
-    };
+    }
+};
 
-    // ---- wave A: the RPS rows of my SIMD of tile k -> buffer `buf` (one descriptor per row, SALU only) ----
-    auto dma = [&](int64_t k, int buf) {
-        const int nrow = (VT_MABL & 2) ? 0 : nrow_of(k);
-        const int64_t rb = nrow > 0 ? first_row(k) : 0;
-        const double* xb = a.X + (rb + RPS * SIMD) * a.ldx;
-#pragma unroll
-        for (int rr = 0; rr < RPS; ++rr) {
-            const int row = RPS * SIMD + rr;
-            __amdgpu_buffer_rsrc_t xrs = mid_rsrc(xb + (int64_t)rr * a.ldx, row < nrow ? 8u * a.D : 0u);
-            double* dst = lds + LY::kTile + buf * (TR * RS) + row * RS;
-#pragma unroll
-            for (int h = 0; h < DMAH; ++h) {
-                const int chunk = 64 * h + lane;
-                if (chunk < CH)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (mid_ldsptr)(dst + 128 * h), 16, 16u * chunk, 0, 0, 0);
-            }
-        }
-        if (lane < 2 * RPS) {
-            const unsigned vo = 8u * (RPS * SIMD) + 4u * lane;
-            const int so = buf * TR + RPS * SIMD;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(mid_rsrc(a.y + rb, 8u * nrow), (mid_ldsptr)(lds + LY::kY + so), 4, vo, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(mid_rsrc(a.w + rb, 8u * nrow), (mid_ldsptr)(lds + LY::kW + so), 4, vo, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(mid_rsrc(a.offset + rb, a.offset ? 8u * nrow : 0u),
-                                                     (mid_ldsptr)(lds + LY::kOff + so), 4, vo, 0, 0, 0);
-        }
-    };
-
-    // ---- wave B: link the RPS rows [RPS*SIMD, RPS*(SIMD+1)) of tile k in buffer `buf` ----
-    const double* th = lds + LY::kTheta;
-    double* zs = lds + LY::kScratch + SIMD * 32;
-    const int trow = RPS * SIMD + (lane & 15);
-    const bool tlane = lane < RPS;
-    const int trow_c = trow < TR ? trow : TR - 1;
+// LINK of the RPS rows [RPS*simd, RPS*(simd+1)) of a tile (a service wave, or wave B of the SIMD).
+template <int NB, bool LOWREG>
+struct MidLink {
+    using LY = MidLds<NB>;
+    static constexpr int RS = LY::RS, TR = LY::TR, RPS = TR / 4, PASSES = (RPS + 3) / 4;
     // gradient: lane l accumulates columns l, l + 64, ... over the rows this wave links (4 accumulators instead of
     // the NB a (row group, column) lane would need: the B waves have no registers to spare)
-    constexpr int CPL = (NB * 16 + 63) / 64;
+    static constexpr int CPL = (NB * 16 + 63) / 64;
     double gacc[CPL];
+
+    __device__ __forceinline__ void init() {
 #pragma unroll
-    for (int m = 0; m < CPL; ++m) gacc[m] = 0.0;
-    auto link = [&](int64_t k, int buf) {
-        const int nrow = nrow_of(k);
-        const int64_t rb = nrow > 0 ? first_row(k) : 0;
+        for (int m = 0; m < CPL; ++m) gacc[m] = 0.0;
+    }
+    __device__ __forceinline__ void link(const MidArgs& a, double* lds, const MidRows<TR>& tiles, int simd, int64_t k, int buf) {
+        const int lane = threadIdx.x & 63;
+        const int q = lane >> 4, c = lane & 15;
+        const double* th = lds + LY::kTheta;
+        double* zs = lds + LY::kScratch + simd * 32;
+        const int trow = RPS * simd + (lane & 15);
+        const bool tlane = lane < RPS;
+        const int trow_c = trow < TR ? trow : TR - 1;
+        const int nrow = tiles.nrow(k);
+        const int64_t rb = nrow > 0 ? tiles.first_row(k) : 0;
         // stage 1: z_n = x_n . theta (16 lanes per row)
 #pragma unroll
         for (int k2 = 0; k2 < PASSES; ++k2) {
             const int rl = min(4 * k2 + q, RPS - 1);
-            const double* tr = lds + LY::kTile + buf * (TR * RS) + (RPS * SIMD + rl) * RS + c;
-            double pz = 0.0;
+            const double* tr = lds + LY::kTile + buf * (TR * RS) + (RPS * simd + rl) * RS + c;
+            double pz0 = 0.0, pz1 = 0.0;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                pz = fma(tr[16 * b], th[16 * b + c], pz);
+                if (!LOWREG && (b & 1)) pz1 = fma(tr[16 * b], th[16 * b + c], pz1);
+                else pz0 = fma(tr[16 * b], th[16 * b + c], pz0);
                 // (4 blocks of loads in flight at a time: hoisted to the top, the 2 NB operands of every pass cost
                 // the B waves more registers than their accumulators)
-                if ((b & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                if (LOWREG && (b & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            const double z = vt_sum16_dpp(pz);
+            const double z = vt_sum16_dpp(pz0 + pz1);
             if (c == 0) zs[4 * k2 + q] = z;
         }
         // stage 2: the scalar chain, one lane per row
@@ -235,12 +206,93 @@ __device__ __forceinline__ void mid_wave(const MidArgs& a, double* lds, int64_t 
 #pragma unroll
         for (int rr = 0; rr < RPS; ++rr) {
             const double gwt = zs[16 + rr];
-            const double* tr = lds + LY::kTile + buf * (TR * RS) + (RPS * SIMD + rr) * RS + lane;
+            const double* tr = lds + LY::kTile + buf * (TR * RS) + (RPS * simd + rr) * RS + lane;
 #pragma unroll
             for (int m = 0; m < CPL; ++m) gacc[m] = fma(gwt, tr[64 * m], gacc[m]);
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    // the wave's column sums -> its slot of gl [4][NB*16] (after every tile is dead)
+    __device__ __forceinline__ void store(double* gl, int simd) const {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int m = 0; m < CPL; ++m)
+            if (64 * m + lane < NB * 16) gl[simd * (NB * 16) + 64 * m + lane] = gacc[m];
+    }
+};
+
+// SERVICE wave (SVC kernels: waves 8..11, one per SIMD): links tile p + 1 in period p, nothing else.
+template <int NB>
+__device__ __forceinline__ void mid_service(const MidArgs& a, double* lds, int64_t mine, int simd) {
+    using LY = MidLds<NB>;
+    const MidRows<LY::TR> tiles{a, mine};
+    MidLink<NB, false> lk;
+    lk.init();
+    vt_lds_barrier();                  // tile 0 has landed
+    if (!(VT_MABL & 4)) lk.link(a, lds, tiles, simd, 0, 0);
+    vt_lds_barrier();
+    int b1 = 1;                        // buffer of tile p + 1
+    for (int64_t p = 0; p < mine; ++p) {
+        if (!(VT_MABL & 4)) lk.link(a, lds, tiles, simd, p + 1, b1);
+        vt_lds_barrier();
+        b1 = b1 == 2 ? 0 : b1 + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every tile is dead
+    lk.store(lds, simd);
+}
+
+// Owner wave O (0..7) on SIMD O & 3.  O < 4 also issues the SIMD's share of the DMA; without service waves O >= 4
+// links the SIMD's rows before its MFMAs.
+template <int NB, int NS, int O, bool SVC>
+__device__ __forceinline__ void mid_wave(const MidArgs& a, double* lds, int64_t mine) {
+    using LY = MidLds<NB>;
+    constexpr int RS = LY::RS, TR = LY::TR;
+    constexpr bool DMA = O < 4, LINK = !SVC && O >= 4;
+    constexpr int SIMD = O & 3;
+    constexpr int KSTEPS = TR / 4;
+    constexpr int RPS = TR / 4;                        // rows of a tile per SIMD (DMA share, link share)
+    constexpr int CH = RS / 2;                         // 16-byte chunks per LDS row
+    constexpr int DMAH = (CH + 63) / 64;               // DMA instructions per row
+    constexpr MidTab TAB = make_mid_tab(NB, NS, SVC ? 0 : VT_MID_LINK_DELTA);
+    constexpr unsigned long long W0 = TAB.own[O][0], W1 = TAB.own[O][1], W2 = TAB.own[O][2];
+    constexpr unsigned NEED = TAB.rows[O] | TAB.cols[O], COLS = TAB.cols[O];
+    constexpr bool STRIP = TAB.strip[O];
+    constexpr int NOWN = TAB.nown[O];
+    static_assert(2 * RPS <= 64, "one DMA instruction moves a SIMD's per-row scalars");
+
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, c = lane & 15;
+    const MidRows<TR> tiles{a, mine};
+
+    // the RPS rows of my SIMD of tile k -> buffer `buf` (one descriptor per row, SALU only)
+    auto dma = [&](int64_t k, int buf) {
+        const int nrow = (VT_MABL & 2) ? 0 : tiles.nrow(k);
+        const int64_t rb = nrow > 0 ? tiles.first_row(k) : 0;
+        const double* xb = a.X + (rb + RPS * SIMD) * a.ldx;
+#pragma unroll
+        for (int rr = 0; rr < RPS; ++rr) {
+            const int row = RPS * SIMD + rr;
+            __amdgpu_buffer_rsrc_t xrs = mid_rsrc(xb + (int64_t)rr * a.ldx, row < nrow ? 8u * a.D : 0u);
+            double* dst = lds + LY::kTile + buf * (TR * RS) + row * RS;
+#pragma unroll
+            for (int h = 0; h < DMAH; ++h) {
+                const int chunk = 64 * h + lane;
+                if (chunk < CH)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (mid_ldsptr)(dst + 128 * h), 16, 16u * chunk, 0, 0, 0);
+            }
+        }
+        if (lane < 2 * RPS) {
+            const unsigned vo = 8u * (RPS * SIMD) + 4u * lane;
+            const int so = buf * TR + RPS * SIMD;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(mid_rsrc(a.y + rb, 8u * nrow), (mid_ldsptr)(lds + LY::kY + so), 4, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(mid_rsrc(a.w + rb, 8u * nrow), (mid_ldsptr)(lds + LY::kW + so), 4, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(mid_rsrc(a.offset + rb, a.offset ? 8u * nrow : 0u),
+                                                     (mid_ldsptr)(lds + LY::kOff + so), 4, vo, 0, 0, 0);
+        }
     };
+
+    MidLink<NB, true> lk;
+    lk.init();
 
     // ---- accumulators: one f64x4 per owned block (a strip block only touches components 0..NS-1) ----
     f64x4 acc[NOWN > 0 ? NOWN : 1];
@@ -251,20 +303,20 @@ __device__ __forceinline__ void mid_wave(const MidArgs& a, double* lds, int64_t 
     // period -1 (peeled, so that the accumulators live in ONE loop nest: with the `p >= 0` test inside the loop
     // hipcc kept a second copy of them for the first iteration and spilled): tile 0 lands, then tile 1 is
     // fetched while tile 0 is linked
-    if (TYPE == 0) {
+    if (DMA) {
         dma(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     vt_lds_barrier();
-    if (TYPE == 0) dma(1, 1);
-    if (TYPE == 1 && !(VT_MABL & 4)) link(0, 0);
-    if (TYPE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (DMA) dma(1, 1);
+    if (LINK && !(VT_MABL & 4)) lk.link(a, lds, tiles, SIMD, 0, 0);
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     vt_lds_barrier();
     int b0 = 0;                        // buffer of tile p
     int b1 = 1;                        // buffer of tile p + 1
     for (int64_t p = 0; p < mine; ++p) {
-        if (TYPE == 0) dma(p + 2, b0 == 0 ? 2 : b0 - 1);   // buffer (p + 2) % 3 == buffer of tile p - 1
-        if (TYPE == 1 && !(VT_MABL & 4)) link(p + 1, b1);
+        if (DMA) dma(p + 2, b0 == 0 ? 2 : b0 - 1);   // buffer (p + 2) % 3 == buffer of tile p - 1
+        if (LINK && !(VT_MABL & 4)) lk.link(a, lds, tiles, SIMD, p + 1, b1);
         if (NOWN > 0 && !(VT_MABL & 1)) {
             // operand reads are inline asm: as compiler-visible LDS loads they make hipcc wait for this wave's own
             // LDS-DMA (vmcnt(0): it cannot tell the tile buffers apart)
@@ -321,21 +373,16 @@ __device__ __forceinline__ void mid_wave(const MidArgs& a, double* lds, int64_t 
         }
         __builtin_amdgcn_sched_barrier(0);
         // my DMA of tile p + 2 has had the whole period: landed before the barrier, so it can be linked next period
-        if (TYPE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         vt_lds_barrier();
         b0 = b0 == 2 ? 0 : b0 + 1;
         b1 = b1 == 2 ? 0 : b1 + 1;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every tile is dead
-    // gradient: the link wave's column sums -> its slot
-    if (TYPE == 1) {
-        double* gl = lds;              // [4][NB*16]
-#pragma unroll
-        for (int m = 0; m < CPL; ++m)
-            if (64 * m + lane < NB * 16) gl[SIMD * (NB * 16) + 64 * m + lane] = gacc[m];
-    }
+    if (LINK) lk.store(lds, SIMD);
     // H: every block has ONE owner, so the accumulators go straight to the workgroup's slab (accumulator layout,
     // block order tri(i, j): what k_hess_finalize reads)
+    constexpr int NBT = NB * (NB + 1) / 2;
     double* out = a.part + (int64_t)blockIdx.x * (NBT * 256 + NB * 16);
 #pragma unroll
     for (int j = 0; j < NB; ++j)
@@ -350,34 +397,36 @@ __device__ __forceinline__ void mid_wave(const MidArgs& a, double* lds, int64_t 
             }
 }
 
-template <int NB, int NS>
-__global__ __launch_bounds__(512) void k_glm_hess_mid(MidArgs a) {
+template <int NB, int NS, bool SVC>
+__global__ __launch_bounds__(SVC ? 768 : 512) void k_glm_hess_mid(MidArgs a) {
     using LY = MidLds<NB>;
     constexpr int NBT = NB * (NB + 1) / 2;
+    constexpr int NT = SVC ? 768 : 512;
     extern __shared__ double lds[];
-    for (int t = threadIdx.x; t < NB * 16; t += 512) lds[LY::kTheta + t] = t < a.D ? a.theta[t] : 0.0;
-    for (int t = threadIdx.x; t < 4 * 32; t += 512) lds[LY::kScratch + t] = 0.0;
+    for (int t = threadIdx.x; t < NB * 16; t += NT) lds[LY::kTheta + t] = t < a.D ? a.theta[t] : 0.0;
+    for (int t = threadIdx.x; t < 4 * 32; t += NT) lds[LY::kScratch + t] = 0.0;
     __syncthreads();
     const int64_t ntiles = (a.N + LY::TR - 1) / LY::TR;
     const int64_t mine = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef VT_MID_ONLYO
-    mid_wave<NB, NS, VT_MID_ONLYO>(a, lds, mine);
+    mid_wave<NB, NS, VT_MID_ONLYO, SVC>(a, lds, mine);
 #else
-    switch (wid) {   // owner = 4 type + SIMD (waves go to the SIMDs in cyclic order)
-        case 0: mid_wave<NB, NS, 0>(a, lds, mine); break;
-        case 1: mid_wave<NB, NS, 1>(a, lds, mine); break;
-        case 2: mid_wave<NB, NS, 2>(a, lds, mine); break;
-        case 3: mid_wave<NB, NS, 3>(a, lds, mine); break;
-        case 4: mid_wave<NB, NS, 4>(a, lds, mine); break;
-        case 5: mid_wave<NB, NS, 5>(a, lds, mine); break;
-        case 6: mid_wave<NB, NS, 6>(a, lds, mine); break;
-        default: mid_wave<NB, NS, 7>(a, lds, mine); break;
+    switch (wid) {   // owner = wave (waves go to the SIMDs in cyclic order)
+        case 0: mid_wave<NB, NS, 0, SVC>(a, lds, mine); break;
+        case 1: mid_wave<NB, NS, 1, SVC>(a, lds, mine); break;
+        case 2: mid_wave<NB, NS, 2, SVC>(a, lds, mine); break;
+        case 3: mid_wave<NB, NS, 3, SVC>(a, lds, mine); break;
+        case 4: mid_wave<NB, NS, 4, SVC>(a, lds, mine); break;
+        case 5: mid_wave<NB, NS, 5, SVC>(a, lds, mine); break;
+        case 6: mid_wave<NB, NS, 6, SVC>(a, lds, mine); break;
+        case 7: mid_wave<NB, NS, 7, SVC>(a, lds, mine); break;
+        default: mid_service<NB>(a, lds, mine, wid & 3); break;
     }
 #endif
     __syncthreads();
     double* out = a.part + (int64_t)blockIdx.x * (NBT * 256 + NB * 16);
-    for (int t = threadIdx.x; t < NB * 16; t += 512) {
+    for (int t = threadIdx.x; t < NB * 16; t += NT) {
         double s2 = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s2 += lds[w * (NB * 16) + t];
@@ -388,11 +437,17 @@ __global__ __launch_bounds__(512) void k_glm_hess_mid(MidArgs a) {
 template <int NB>
 constexpr size_t mid_lds_bytes() { return (size_t)MidLds<NB>::kTotal * sizeof(double); }
 
+#ifndef VT_MID_SVC_NB
+#define VT_MID_SVC_NB 13
+#endif
+constexpr int kMidSvcNB = VT_MID_SVC_NB;   // largest NB whose owners fit the 168 registers of three waves per SIMD
+
 template <int NB, int NS>
 int launch_mid2(const MidArgs& a, int grid, hipStream_t st) {
+    constexpr bool SVC = NB <= kMidSvcNB;
     static VtLdsAttr attr;   // per kernel instantiation, per device
-    if (vt_allow_big_lds((const void*)k_glm_hess_mid<NB, NS>, attr, 160 * 1024) != VT_OK) return VT_ERR_HIP;
-    hipLaunchKernelGGL((k_glm_hess_mid<NB, NS>), dim3(grid), dim3(512), mid_lds_bytes<NB>(), st, a);
+    if (vt_allow_big_lds((const void*)k_glm_hess_mid<NB, NS, SVC>, attr, 160 * 1024) != VT_OK) return VT_ERR_HIP;
+    hipLaunchKernelGGL((k_glm_hess_mid<NB, NS, SVC>), dim3(grid), dim3(SVC ? 768 : 512), mid_lds_bytes<NB>(), st, a);
     return VT_OK;
 }
 
