@@ -52,6 +52,12 @@ def parse():
     p.add_argument("--no-block", action="store_true", help="skip the block-sparse VI side measurement (configs[4])")
     p.add_argument("--block-groups", type=int, default=10_000)
     p.add_argument("--no-fp32", action="store_true", help="skip the fp32 storage-mode side measurement (row n1)")
+    p.add_argument("--no-c3", action="store_true", help="skip the configs[2] leg (D = 1000)")
+    p.add_argument("--c3-rows", type=int, default=0,
+                   help="TOTAL rows of the configs[2] leg (default: 1.25e6 on one GPU = an 8-GPU job's share, 1e7 over N > 1 GPUs)")
+    p.add_argument("--c3-dim", type=int, default=1000)
+    p.add_argument("--no-c4", action="store_true", help="skip the multi-rank configs[3] leg (N > 1 only)")
+    p.add_argument("--c4-rows", type=int, default=500_000, help="TOTAL rows of the multi-rank configs[3] leg")
     return p.parse_args()
 
 
@@ -388,6 +394,193 @@ def fp32_side_measurement(torch, va, DeviceCholesky, X, y, w, theta, prior, H64,
     return res
 
 
+def _max_over_ranks(torch, dist, world, coll_dev, x):
+    t = torch.tensor([float(x)], dtype=torch.float64, device=coll_dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def config3_leg(torch, dist, va, DeviceCholesky, world, rank, device, group, coll_dev, rows_total, dim, reps=3):
+    """BASELINE.json configs[2] (weighted logistic GLM, D = 1000; N = 10^7 over the whole job), rank-symmetric:
+    every rank holds rows_total / world rows of ONE Philox data set, theta-hat by the device Newton optimiser,
+    then Hessian (+ all-reduce of [H | g]) -> Cholesky + pack -> all-rows TRSM, timed per stage with HIP events
+    and as a whole (barrier + max over ranks).  At world == 1 the default is the 1/8 share an 8-GPU job gives one
+    card (1.25e6 rows); at world > 1 it is the strong-scaled 10^7 rows.  Parity through size-independent
+    properties: sampled rows of S regenerated on the host against SciPy's cho_solve, the all-rows checksum
+    sum_n w_n S[n, :] == -H^{-1} (g - prior theta), H of the first rows against NumPy, and H identical on all
+    ranks after the all-reduce."""
+    import scipy.linalg
+    from vittles_amd import rows as vrows
+    seed = 3
+    n_local = rows_total // world
+    N = n_local * world
+    X, y, _ = va.synth.glm_problem(n_local, dim, "logistic", seed=seed, row0=rank * n_local, device=device)
+    w = torch.ones(n_local, dtype=torch.float64, device=device)
+    obj = va.WeightedGLMObjective(X, y, family="logistic", prior=1.0, process_group=group)
+    t0 = time.perf_counter()
+    theta, info = va.optim.newton_glm(obj, w, grad_tol=1e-9)
+    torch.cuda.synchronize()
+    t_newton = time.perf_counter() - t0
+    S = torch.empty((n_local, dim), dtype=torch.float64, device=device)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(reps)]
+    cur = [None]
+
+    def hook(name):
+        if cur[0] is not None:
+            ev[cur[0]][4 if name == "allreduce_begin" else 5].record()
+    obj.stage_hook = hook if world > 1 else None
+
+    def step(i=None):
+        obj.invalidate_cache()
+        cur[0] = i
+        if i is not None:
+            ev[i][0].record()
+        out = obj.fused(theta, w)
+        if i is not None:
+            ev[i][1].record()
+        chol = DeviceCholesky.factor(out["H"], check=False, pack=True)
+        if i is not None:
+            ev[i][2].record()
+        chol.solve_rows(X, rowscale=out["r"], alpha=-1.0, out=S)
+        if i is not None:
+            ev[i][3].record()
+        chol.raise_if_failed()
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(reps):
+        out = step(i)
+    barrier()
+    dt = _max_over_ranks(torch, dist, world, coll_dev, (time.perf_counter() - t0) / reps)
+    cur[0] = None
+    obj.stage_hook = None
+    ms_h = float(np.median([e[0].elapsed_time(e[1]) for e in ev]))
+    ms_c = float(np.median([e[1].elapsed_time(e[2]) for e in ev]))
+    ms_t = float(np.median([e[2].elapsed_time(e[3]) for e in ev]))
+    ms_ar = float(np.median([e[4].elapsed_time(e[5]) for e in ev])) if world > 1 else 0.0
+    ms_syrk = ms_h - ms_ar
+    # ---- parity ----
+    Hh = out["H"].cpu().numpy()
+    gh = out["g"].cpu().numpy()
+    th = theta.cpu().numpy()
+    cf = scipy.linalg.cho_factor(Hh)
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    idx = np.unique(np.linspace(0, n_local - 1, 500).astype(np.int64))
+    Xs, ys = va.synth.glm_rows_host(N, dim, "logistic", seed, idx + rank * n_local)
+    di = torch.as_tensor(idx, device=device)
+    regen = float(np.abs(X[di].cpu().numpy() - Xs).max())
+    pr = 1.0 / (1.0 + np.exp(-(Xs @ th)))
+    S_ref = -scipy.linalg.cho_solve(cf, (Xs * (pr - ys)[:, None]).T).T
+    err_rows = _max_over_ranks(torch, dist, world, coll_dev, rel(S[di].cpu().numpy(), S_ref))
+    lhs = vrows.gemv_t(S, w)
+    obj._all_reduce(lhs)
+    err_sum = rel(lhs.cpu().numpy(), -scipy.linalg.cho_solve(cf, gh - 1.0 * th))
+    hs = torch.tensor([float(out["H"].sum().item()), float(out["H"].abs().sum().item())], dtype=torch.float64,
+                      device=coll_dev)
+    same = True
+    if world > 1:
+        allh = [torch.zeros_like(hs) for _ in range(world)]
+        dist.all_gather(allh, hs)
+        same = all(bool(torch.equal(a, allh[0])) for a in allh)
+    res = None
+    if rank == 0:
+        n_sub = min(n_local, 20_000)
+        sub = va.WeightedGLMObjective(X[:n_sub], y[:n_sub], family="logistic", prior=1.0)
+        H_sub = sub.fused(theta, w[:n_sub])["H"].cpu().numpy()
+        Xh = X[:n_sub].cpu().numpy()
+        ph = 1.0 / (1.0 + np.exp(-(Xh @ th)))
+        H_ref = Xh.T @ ((ph * (1 - ph))[:, None] * Xh) + np.eye(dim)
+        syrk_tf = float(n_local) * dim * (dim + 1) / (ms_syrk * 1e-3) / 1e12
+        trsm_tf = 2.0 * dim * dim * n_local / (ms_t * 1e-3) / 1e12
+        res = {"workload": "weighted logistic GLM D=%d, %d rows per GPU x %d GPU(s) = %d rows (configs[2]%s), fp64"
+                           % (dim, n_local, world, N, "" if N >= 10_000_000 else ": the share one of 8 GPUs holds"
+                              if N == 1_250_000 and world == 1 else ", reduced rows"),
+               "rows_per_gpu": n_local, "rows_total": N, "dim": dim, "n_gpus": world,
+               "scaling": "strong" if world > 1 else "one share",
+               "stages_ms": {"fused_link_grad_hessian": ms_syrk, "all_reduce_H_g": ms_ar, "cholesky_pack": ms_c,
+                             "sens_trsm": ms_t},
+               "seconds_all_sensitivities": dt, "sensitivities_per_s": N / dt,
+               "syrk_TFLOPs": syrk_tf, "syrk_frac_of_peak": syrk_tf / FP64_MFMA_PEAK_TFLOPS,
+               "trsm_TFLOPs": trsm_tf, "trsm_frac_of_peak": trsm_tf / FP64_MFMA_PEAK_TFLOPS,
+               "flops_note": "per GPU; SYRK = N D (D+1) (the triangle), TRSM = 2 D^2 N; peak %.1f TFLOP/s fp64 MFMA"
+                             % FP64_MFMA_PEAK_TFLOPS,
+               "newton": {"seconds": t_newton, "iterations": int(info["iterations"]),
+                          "grad_norm": float(info["grad_norm"])},
+               "parity": {"S_sampled_rows_rel_err_max_over_ranks": err_rows, "sampled_rows_per_rank": int(len(idx)),
+                          "regenerated_rows_max_abs_diff": regen,
+                          "checksum_all_rows_rel_err": err_sum,
+                          "H_first_rows_rel_err_vs_numpy": rel(H_sub, H_ref), "H_first_rows": int(n_sub),
+                          "H_identical_on_all_ranks": bool(same), "tolerance": 1e-9}}
+    del X, S, obj
+    torch.cuda.empty_cache()
+    return res
+
+
+def config4_leg(torch, dist, va, world, rank, device, group, coll_dev, rows_total, dim, tol=1e-5):
+    """BASELINE.json configs[3] (matrix-free CG, D = 20000 ridge-logistic, N = 5*10^5 over the whole job),
+    rank-symmetric: row-sharded fused HVP + one all-reduce of the D-vector per CG iteration.  Reports the solve,
+    the local HVP kernel and the collective timed on its own."""
+    from vittles_amd import rows as vrows, cg
+    n_local = rows_total // world
+    N = n_local * world
+    X, y, theta_star = va.synth.glm_problem(n_local, dim, "logistic", seed=4, row0=rank * n_local, device=device)
+    w = torch.ones(n_local, dtype=torch.float64, device=device)
+    obj = va.WeightedGLMObjective(X, y, family="logistic", prior=1.0, process_group=group)
+    theta = 0.5 * theta_star
+    hvp = cg.GLMHessianVectorProduct(obj, theta, w)
+    _, r, _ = vrows.glm_link(obj, theta, w)
+    dw = va.synth.normal_rows(5, rank * n_local, n_local, 2, device=device)[:, 0].contiguous()
+    b = vrows.gemv_t2(X, r, dw)
+    obj._all_reduce(b)
+    v = torch.as_tensor(va.synth.theta_star_host(6, dim), device=device)
+    out = torch.empty_like(v)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    ms_local = timed(lambda: vrows.glm_hvp(obj.X, hvp.d, v, prior=None, out=out), 10)
+    ms_ar = timed(lambda: obj._all_reduce(out), 20)
+    ms_apply = timed(lambda: hvp.apply(v, out), 10)
+    cg.cg_solve(lambda p_, o_: hvp.apply(p_, o_), b, tol=tol, maxiter=3)     # warm-up
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x, info, iters = cg.cg_solve(lambda p_, o_: hvp.apply(p_, o_), b, tol=tol)
+    torch.cuda.synchronize()
+    dt = _max_over_ranks(torch, dist, world, coll_dev, time.perf_counter() - t0)
+    resid = float(((hvp.apply(x) - b).norm() / b.norm()).item())
+    res = None
+    if rank == 0:
+        nbytes = 8.0 * n_local * dim + 8.0 * n_local + 16.0 * dim
+        res = {"workload": "matrix-free CG, ridge-logistic D=%d, %d rows per GPU x %d GPU(s) = %d rows (configs[3]), "
+                           "tol=%g" % (dim, n_local, world, N, tol),
+               "rows_per_gpu": n_local, "rows_total": N, "dim": dim, "n_gpus": world, "scaling": "strong",
+               "cg_seconds": dt, "cg_iterations": int(iters), "cg_info": int(info), "true_residual_rel": resid,
+               "ms_per_iteration": dt / max(iters, 1) * 1e3,
+               "hvp_local_kernel_ms": ms_local, "hvp_local_GBs": nbytes / (ms_local * 1e-3) / 1e9,
+               "hvp_local_frac_of_hbm_peak": nbytes / (ms_local * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "all_reduce_D_vector_ms": ms_ar, "all_reduce_bytes": 8 * dim,
+               "hvp_with_all_reduce_ms": ms_apply,
+               "row_iterations_per_s": N * max(iters, 1) / dt}
+    del X, obj, hvp
+    torch.cuda.empty_cache()
+    return res
+
+
+
 def note(msg):
     if os.environ.get("VITTLES_BENCH_VERBOSE"):
         print("[bench rank %s %.1fs] %s" % (os.environ.get("RANK", "0"), time.perf_counter(), msg),
@@ -548,9 +741,12 @@ def main():
         allt = [torch.zeros_like(tl) for _ in range(world)]
         dist.all_gather(allt, tl)
         per_rank = [float(t.item()) for t in allt]
-        ones = torch.ones(1, dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(ones)
-        seen = int(round(float(ones.item())))
+        if backend == "nccl":      # counted through an RCCL collective only (a gloo rehearsal reports null)
+            ones = torch.ones(1, dtype=torch.float64, device=device)
+            dist.all_reduce(ones)
+            seen = int(round(float(ones.item())))
+        else:
+            seen = None
     dt = max(per_rank)          # MAX over ranks
 
     ms_hess = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
@@ -558,6 +754,15 @@ def main():
     ms_trsm = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
     ms_ar = float(np.mean([e[4].elapsed_time(e[5]) for e in ev])) if world > 1 else 0.0
 
+    leg3 = leg4 = None
+    if world > 1:
+        if not args.no_c3:
+            note("configs[2] leg")
+            leg3 = config3_leg(torch, dist, va, DeviceCholesky, world, rank, device, group, coll_dev,
+                               args.c3_rows or 10_000_000, args.c3_dim)
+        if not args.no_c4:
+            note("configs[3] leg")
+            leg4 = config4_leg(torch, dist, va, world, rank, device, group, coll_dev, args.c4_rows, args.hvp_dim)
     if rank == 0:
         traffic, traffic_source = latest_traffic(N, D)
         ms_per_step = dt / args.steps * 1e3
@@ -576,9 +781,10 @@ def main():
                                    "(Hessian SYRK + multi-RHS TRSM), ridge prior 1" % (N, D),
                        "rows_per_gpu": N, "dim": D, "parallelism": "row-sharded dp%d" % world,
                        "backend": backend if world > 1 else None,
+                       "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
                        "grad_norm_at_theta_hat": grad_norm},
             "clock_ramp_steps": n_ramp + 21, "cold_ms_per_step": cold_ms,
-            "rccl_ranks_seen": seen, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
+            "rccl_ranks_seen": seen, "ranks": world, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
             "roofline": {"bound": "mfma", "kernel": "k_trsm_rows_small (K2+K5 sens TRSM)",
                          "achieved": trsm_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": trsm_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
@@ -628,12 +834,19 @@ def main():
                                                             out["H"], S)
             del S, X
             torch.cuda.empty_cache()
+            if not args.no_c3:
+                result["config3_share"] = config3_leg(torch, dist, va, DeviceCholesky, 1, 0, device, None, coll_dev,
+                                                      args.c3_rows or 1_250_000, args.c3_dim)
             if not args.no_hvp:
                 result["hvp"], result["cg"] = hvp_cg_side_measurement(torch, device, args.hvp_rows, args.hvp_dim,
                                                                       args.cg_cpu_rows)
                 torch.cuda.empty_cache()
             if not args.no_block:
                 result["block"] = block_side_measurement(torch, args.block_groups)
+        if leg3 is not None:
+            result["config3_strong"] = leg3
+        if leg4 is not None:
+            result["config4_strong"] = leg4
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -47,11 +47,23 @@ def test_bench_gpus2_spawns_two_ranks():
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5",
-                          "--warmup", "1", "--rows", "50000"], env=env, capture_output=True, text=True, timeout=600)
+                          "--warmup", "1", "--rows", "50000", "--c3-rows", "40000", "--c3-dim", "300",
+                          "--c4-rows", "4000", "--hvp-dim", "5000"], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-4000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["rccl_ranks_seen"] == 2
+    assert out["n_gpus"] == 2 and out["ranks"] == 2
+    assert out["rccl_ranks_seen"] is None and out["config"]["collective_backend"] == "gloo"   # no RCCL in a gloo rehearsal
     assert len(out["per_rank_ms_per_step"]) == 2
     assert out["stages_ms"]["all_reduce_H_g"] > 0.0
     assert out["value"] > 0 and out["scaling"] == "weak"
+    # the rank-symmetric legs of configs[2] (strong-scaled dense path) and configs[3] (CG with an all-reduce per iteration)
+    c3 = out["config3_strong"]
+    assert c3["n_gpus"] == 2 and c3["rows_per_gpu"] == 20000 and c3["rows_total"] == 40000
+    assert c3["stages_ms"]["all_reduce_H_g"] > 0.0 and c3["parity"]["H_identical_on_all_ranks"]
+    for key in ("S_sampled_rows_rel_err_max_over_ranks", "checksum_all_rows_rel_err", "H_first_rows_rel_err_vs_numpy"):
+        assert c3["parity"][key] < 1e-9, key
+    assert c3["parity"]["regenerated_rows_max_abs_diff"] < 1e-12
+    c4 = out["config4_strong"]
+    assert c4["n_gpus"] == 2 and c4["cg_info"] == 0 and c4["true_residual_rel"] < 1e-4
+    assert c4["all_reduce_D_vector_ms"] > 0.0 and c4["cg_iterations"] > 0
