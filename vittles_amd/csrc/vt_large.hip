@@ -165,10 +165,18 @@ __global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
     constexpr int PA = (kT / 8) * kRB;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;   // 2 x 4 waves of 64 x 32
     const int q = lane >> 4, c = lane & 15;
     const int n0 = blockIdx.y * kT;
     const int nrem = min(kT, a.N - n0);
+    // Wave grid over the 128 x nrem tile (workgroup-uniform): 2 x 4 waves of 64 x 32; a remainder panel of at most
+    // 64 / 32 columns is dealt as 4 x 2 waves of 32 x 32 / 8 x 1 waves of 16 x 32, so that every SIMD keeps work and
+    // nobody multiplies the zero padding (round 2 computed the full 128 columns for a 1-column remainder).
+    const int narrow = nrem > 64 ? 0 : nrem > 32 ? 1 : 2;
+    const int wm = narrow == 0 ? wave >> 2 : narrow == 1 ? wave >> 1 : wave;
+    const int wn = narrow == 0 ? wave & 3 : narrow == 1 ? wave & 1 : 0;
+    const int rpw = 64 >> narrow;                                    // rows per wave
+    const int ni = 4 >> narrow;                                      // 16-row blocks per wave
+    const int nj = min(2, max(0, (nrem - 32 * wn + 15) >> 4));       // 16-column blocks per wave
     const int nk = (a.K + kKC - 1) / kKC;
     const int64_t ntiles = (a.M + kT - 1) / kT;
 
@@ -232,22 +240,24 @@ __global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             // operand of lane (c = row, q = k) for k-step s: plane kp = 2 s + (q >> 1), element q & 1
-            const double* pa = lds + buf * kGemmStage + (8 * wm + (c >> 3)) * kRB + (q >> 1) * 16 + (c & 7) * 2 + (q & 1);
+            const double* pa = lds + buf * kGemmStage + ((rpw >> 3) * wm + (c >> 3)) * kRB + (q >> 1) * 16 + (c & 7) * 2 + (q & 1);
             const double* pb = lds + buf * kGemmStage + PA + (4 * wn + (c >> 3)) * kRB + (q >> 1) * 16 + (c & 7) * 2 + (q & 1);
+            if (nj > 0) {   // (scalar branches: a remainder panel multiplies only its real blocks)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                double af[4], bf[2];
+                for (int s = 0; s < 4; ++s) {
+                    double af[4], bf[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = pa[s * 32 + 2 * kRB * i];
+                    for (int i = 0; i < 4; ++i) af[i] = i < ni ? pa[s * 32 + 2 * kRB * i] : 0.0;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = pb[s * 32 + 2 * kRB * j];
+                    for (int j = 0; j < 2; ++j) bf[j] = pb[s * 32 + 2 * kRB * j];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if (VT_LABL & 2) acc[i][j][0] += af[i] * bf[j]; else
-                        acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
-                    }
+                        for (int j = 0; j < 2; ++j) {
+                            if (VT_LABL & 2) acc[i][j][0] += af[i] * bf[j]; else
+                            if (i < ni && j < nj) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+                        }
+                }
             }
             buf ^= 1;
         }
@@ -257,10 +267,11 @@ __global__ __launch_bounds__(512) void k_gemm_nt_lds(GemmArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                if (i >= ni || j >= nj) continue;
                 const int n = n0 + 32 * wn + 16 * j + c;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int64_t m = m0 + 64 * wm + 16 * i + q + 4 * r;
+                    const int64_t m = m0 + rpw * wm + 16 * i + q + 4 * r;
                     if (m < a.M && n < a.N) {
                         double* p = a.C + m * a.ldc + n;
                         double v = a.alpha * acc[i][j][r];
@@ -323,6 +334,28 @@ int gemm_nt(double* C, int64_t ldc, int64_t M, int N, const double* A, int64_t l
 }
 
 // ------------------------------------------------------------------ SYRK tiles -------
+// (tile, rows) enumeration of a launch.
+//   * XCD-AWARE: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), and every tile's
+//     two 16 x 128 panels per stage are re-read by every other tile of its tile row / column.  Round 2 numbered the
+//     workgroups tile-major, so the tiles that read the same rows of X sat on different XCDs: PMC at N = 1.25e6,
+//     D = 1000 showed an L2 hit rate of 2 % and 82 GB through the fabric for a 10 GB X (3.4 TB/s: the kernel was bound
+//     there, not on the MFMA pipe).  Now XCD x = b & 7 owns the x-th EIGHTH OF THE ROWS for every tile, so its
+//     resident workgroups walk the same rows of X at the same time and share them through the XCD's L2.
+//   * CLASSES: the tiles of the lower triangle fall into four classes of equal cost -- A: full off-diagonal, B: full
+//     diagonal, C: off-diagonal of a partial last tile row, D: the partial last diagonal tile -- and a class's tiles
+//     split their XCD's rows s[c] ways, in proportion to what one k-step of such a tile costs the busiest SIMD
+//     (syrk_tile_cost), so that the workgroups of a launch carry about the same work.  (Round 2 gave every tile the
+//     same split: the launch lasted as long as its fullest tile, and D = 257 paid six full tiles for three.)
+//   Workgroup b = slab b:  x = b & 7, j = b >> 3 in [0, per_xcd);  class c owns j in [off[c], off[c] + n[c] s[c]),
+//   sub-range k = (j - off[c]) / n[c], tile (j - off[c]) % n[c]  (sub-range-major: neighbours in time share rows).
+// The two-operand product (GEN) is one class of nta x ntb rectangular tiles.
+struct SyrkPlan {
+    int n[4];
+    int s[4];
+    int off[4];
+    int per_xcd;
+};
+
 struct SyrkArgs {
     const double* X;
     int64_t ldx;
@@ -330,8 +363,8 @@ struct SyrkArgs {
     int64_t N;
     int D;
     int nt;        // tiles per side
-    int ksplit;
-    double* part;  // [ksplit][ntl][128*128]
+    SyrkPlan plan;
+    double* part;  // [8 plan.per_xcd][128*128]
     // GEN (two-operand) mode:  C = X^T diag(d) B  with B (N x Db); nt x ntb rectangular tile grid
     const void* B;   // double, or float for the fp32 storage mode's S (k_syrk_*<true, ..., float>)
     int64_t ldb;
@@ -339,37 +372,98 @@ struct SyrkArgs {
     int ntb;
 };
 
-// tile index -> (ti, tj): lower triangle (SYRK) or ti * ntb + tj (two-operand product)
+// workgroup -> (class, tile within the class) and its rows [r0, r1) (multiples of 16 but for the very end)
+__host__ __device__ __forceinline__ void plan_locate(const SyrkPlan& p, int64_t N, int wg, int& cls, int& local,
+                                                     int64_t& r0, int64_t& r1) {
+    const int x = wg & 7, j = wg >> 3;
+    cls = 0;
+    while (cls < 3 && j >= p.off[cls] + p.n[cls] * p.s[cls]) ++cls;
+    const int r = j - p.off[cls];
+    const int k = r / p.n[cls];
+    local = r - k * p.n[cls];
+    const int64_t len8 = ((N + 7) / 8 + 15) / 16 * 16;
+    const int64_t x0 = min((int64_t)x * len8, N), x1 = min(N, x0 + len8);
+    const int64_t per = ((x1 - x0 + p.s[cls] - 1) / p.s[cls] + 15) / 16 * 16;
+    r0 = min(x1, x0 + (int64_t)k * per);
+    r1 = min(x1, r0 + per);
+}
+// class-order tile index u in [0, sum n) -> (class, local)
+__host__ __device__ __forceinline__ void plan_tile(const SyrkPlan& p, int u, int& cls, int& local) {
+    cls = 0;
+    while (cls < 3 && u >= p.n[cls]) u -= p.n[cls++];
+    local = u;
+}
+
+// (class, local) -> (ti, tj): lower triangle (SYRK) or ti * ntb + tj (two-operand product)
 template <bool GEN>
-__device__ __forceinline__ void tile_of(const SyrkArgs& a, int t, int& ti, int& tj) {
+__host__ __device__ __forceinline__ void tile_of(int nt, int ntb, int cls, int local, int& ti, int& tj) {
     if constexpr (GEN) {
-        ti = t / a.ntb;
-        tj = t - ti * a.ntb;
+        ti = local / ntb;
+        tj = local - ti * ntb;
+    } else if (cls == 0) {       // off-diagonal tiles of the full tile rows: row ti holds ti of them
+        ti = 1;
+        while (ti * (ti + 1) / 2 <= local) ++ti;
+        tj = local - ti * (ti - 1) / 2;
+    } else if (cls == 1) {
+        ti = tj = local;
+    } else if (cls == 2) {
+        ti = nt - 1;
+        tj = local;
     } else {
-        ti = 0;
-        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-        tj = t - ti * (ti + 1) / 2;
+        ti = tj = nt - 1;
     }
+}
+
+// What wave `wave` (0..7, SIMD wave & 3) of a 128 x 128 tile computes: the 4 x 2 blocks (16 x 16 each) at rows
+// 64 wm + 16 i, columns 32 wn + 16 j whose bit 2 i + j is set in `mask` -- the blocks inside icols x jcols and, on
+// a diagonal tile, not strictly above the diagonal.  Diagonal tiles deal their six non-empty sub-tiles so that the
+// four SIMDs carry 8 / 8 / 10 / 10 blocks (the plain 2 x 4 grid: 16 / 16 / 8 / 8, as long as a full tile).
+struct WaveJob {
+    int wm, wn;
+    unsigned mask;
+};
+__host__ __device__ __forceinline__ WaveJob syrk_wave_job(bool diag, int icols, int jcols, int wave) {
+    WaveJob w{wave >> 2, wave & 3, 0u};
+    if (diag) {
+        //                 wave:  0  1  2  3   4   5  6  7
+        const int wmT = 0x10000111, wnT = 0x31000210;     // nibbles, wave 0 lowest; waves 4 and 5 idle
+        w.wm = (wmT >> (4 * wave)) & 15;
+        w.wn = (wnT >> (4 * wave)) & 15;
+        if (wave == 4 || wave == 5) return WaveJob{0, 0, 0u};
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j) {
+            const int r = 64 * w.wm + 16 * i, c = 32 * w.wn + 16 * j;
+            if (r < icols && c < jcols && (!diag || c <= r)) w.mask |= 1u << (2 * i + j);
+        }
+    return w;
+}
+// MFMA blocks per k-step on the busiest SIMD, plus the stage's fixed share (DMA issue, barrier, operand reads) in
+// the same unit
+inline int syrk_tile_cost(bool diag, int icols, int jcols) {
+    static const int c0 = getenv("VT_SYRK_C0") ? atoi(getenv("VT_SYRK_C0")) : 6;   // dev switch, read once
+    int simd[4] = {0, 0, 0, 0};
+    for (int wv = 0; wv < 8; ++wv) simd[wv & 3] += __builtin_popcount(syrk_wave_job(diag, icols, jcols, wv).mask);
+    return std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3])) + c0;
 }
 
 template <bool GEN, typename BT = double>
 __global__ __launch_bounds__(256) void k_syrk_tile(SyrkArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
-    int t = blockIdx.x, ti, tj;
-    tile_of<GEN>(a, t, ti, tj);
+    int cls, local, ti, tj;
+    int64_t r0, r1;
+    plan_locate(a.plan, a.N, blockIdx.x, cls, local, r0, r1);
+    tile_of<GEN>(a.nt, a.ntb, cls, local, ti, tj);
     const int wm = wave >> 1, wn = wave & 1;
     const int i0 = ti * kT + wm * 64, j0 = tj * kT + wn * 64;
-    const int ntl = GEN ? a.nt * a.ntb : a.nt * (a.nt + 1) / 2;
     const int Dj = GEN ? a.Db : a.D;
-    double* out = a.part + ((int64_t)blockIdx.y * ntl + t) * (kT * kT);
+    double* out = a.part + (int64_t)blockIdx.x * (kT * kT);
     // wave strictly above the diagonal (SYRK) or entirely in the padding
     const bool skip = (!GEN && ti == tj && wn > wm) || i0 >= a.D || j0 >= Dj;
 
-    const int64_t nsteps = (a.N + 3) >> 2;
-    const int64_t per = (nsteps + a.ksplit - 1) / a.ksplit;
-    const int64_t s0 = (int64_t)blockIdx.y * per;
-    const int64_t s1 = min(nsteps, s0 + per);
+    // 4-row steps (a non-empty range starts at a multiple of 16; the last step is masked by n < N)
+    const int64_t s0 = r1 > r0 ? r0 >> 2 : 0, s1 = r1 > r0 ? (r1 + 3) >> 2 : 0;
 
     f64x4 acc[4][4];
 #pragma unroll
@@ -447,21 +541,18 @@ __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
     constexpr int RSTR = kT + 16, PANEL = kKC * RSTR;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
     const int q = lane >> 4, c = lane & 15;
-    int t_id = blockIdx.x, ti, tj;
-    tile_of<GEN>(a, t_id, ti, tj);
-    const int ntl = GEN ? a.nt * a.ntb : a.nt * (a.nt + 1) / 2;
-    double* out = a.part + ((int64_t)blockIdx.y * ntl + t_id) * (kT * kT);
-
-    int64_t per = (a.N + a.ksplit - 1) / a.ksplit;
-    per = (per + kKC - 1) / kKC * kKC;
-    const int64_t r0 = (int64_t)blockIdx.y * per;
-    const int64_t r1 = min(a.N, r0 + per);
+    int cls, local, ti, tj;
+    int64_t r0, r1;
+    plan_locate(a.plan, a.N, blockIdx.x, cls, local, r0, r1);
+    tile_of<GEN>(a.nt, a.ntb, cls, local, ti, tj);
+    double* out = a.part + (int64_t)blockIdx.x * (kT * kT);
     const int nk = r1 > r0 ? (int)((r1 - r0 + kKC - 1) / kKC) : 0;
     const int icols = min(kT, a.D - ti * kT), jcols = min(kT, (GEN ? a.Db : a.D) - tj * kT);
-    // sub-tile strictly above the diagonal (SYRK), or entirely in the zero padding of the tile
-    const bool skip = (!GEN && ti == tj && 32 * wn >= 64 * (wm + 1)) || 64 * wm >= icols || 32 * wn >= jcols;
+    // this wave's blocks of the tile (wave-uniform: everything below branches on scalars)
+    const WaveJob job = syrk_wave_job(!GEN && ti == tj, icols, jcols, wave);
+    const int wm = job.wm, wn = job.wn;
+    const unsigned mask = __builtin_amdgcn_readfirstlane(job.mask);
 
     auto issue = [&](int t, int buf) {
 #pragma unroll
@@ -512,21 +603,25 @@ __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
             issue(t + 1, buf ^ 1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (!skip) {
+        if (mask != 0u) {
             constexpr int BR = (int)(sizeof(double) / sizeof(BT));   // B elements per double of LDS
             const double* pa = lds + buf * (2 * PANEL) + q * RSTR + 64 * wm + c;
             const BT* pb = (const BT*)(lds + buf * (2 * PANEL) + PANEL + q * RSTR) + 32 * wn + c;
+            {   // only the blocks of the mask (scalar branches; a second, unmasked copy of the loop for full tiles cost
+                // 74 more VGPRs and the second workgroup per CU)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                double af[4], bf[2];
+                for (int s = 0; s < 4; ++s) {
+                    double af[4], bf[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = pa[4 * s * RSTR + 16 * i];
+                    for (int i = 0; i < 4; ++i) af[i] = pa[4 * s * RSTR + 16 * i];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = dcur[s] * (double)pb[4 * s * RSTR * BR + 16 * j];
+                    for (int j = 0; j < 2; ++j) bf[j] = dcur[s] * (double)pb[4 * s * RSTR * BR + 16 * j];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+                        for (int j = 0; j < 2; ++j)
+                            if ((mask >> (2 * i + j)) & 1u) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+                }
             }
         }
 #pragma unroll
@@ -535,38 +630,39 @@ __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
         else buf ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (blocks outside the mask are neither written nor read: the reduce kernels stay inside the tile's real rows and
+    // columns and, for a diagonal tile, on or below the diagonal)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
+            if ((mask >> (2 * i + j)) & 1u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                out[(wm * 64 + 16 * i + q + 4 * r) * kT + wn * 32 + 16 * j + c] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r)
+                    out[(wm * 64 + 16 * i + q + 4 * r) * kT + wn * 32 + 16 * j + c] = acc[i][j][r];
+            }
 }
 
 // H[i][j] = H[j][i] = sum_chunks part (+ prior on the diagonal), i >= j.  One thread per element,
 // slabs summed in a fixed order.
-__global__ __launch_bounds__(256) void k_syrk_reduce(const double* part, int nt, int ksplit, int D,
+__global__ __launch_bounds__(256) void k_syrk_reduce(const double* part, int nt, SyrkPlan plan, int D,
                                                      const double* prior, double* H, int ldh) {
-    int t = blockIdx.y, ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tj = t - ti * (ti + 1) / 2;
-    const int ntl = nt * (nt + 1) / 2;
+    int cls, local, ti, tj;
+    plan_tile(plan, blockIdx.y, cls, local);
+    tile_of<false>(nt, 0, cls, local, ti, tj);
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int i = ti * kT + e / kT, j = tj * kT + e % kT;
     if (i >= D || j >= D || j > i) return;
-    const double* p = part + (int64_t)t * (kT * kT) + e;
-    const int64_t stride = (int64_t)ntl * (kT * kT);
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int k = 0;
-    for (; k + 4 <= ksplit; k += 4) {
-        s0 += p[(k + 0) * stride];
-        s1 += p[(k + 1) * stride];
-        s2 += p[(k + 2) * stride];
-        s3 += p[(k + 3) * stride];
+    // the tile's slabs: workgroups x + 8 (off + k n + local), sub-range k, XCD x -- summed in that fixed order
+    double sx[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) sx[x] = 0.0;
+    for (int k = 0; k < plan.s[cls]; ++k) {
+        const double* p = part + (int64_t)(8 * (plan.off[cls] + k * plan.n[cls] + local)) * (kT * kT) + e;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) sx[x] += p[(int64_t)x * (kT * kT)];
     }
-    for (; k < ksplit; ++k) s0 += p[k * stride];
-    double s = (s0 + s1) + (s2 + s3);
+    double s = ((sx[0] + sx[1]) + (sx[2] + sx[3])) + ((sx[4] + sx[5]) + (sx[6] + sx[7]));
     if (i == j && prior) s += prior[i];
     H[(int64_t)i * ldh + j] = s;
     H[(int64_t)j * ldh + i] = s;
@@ -575,25 +671,23 @@ __global__ __launch_bounds__(256) void k_syrk_reduce(const double* part, int nt,
 // C[i][j] = alpha * sum_chunks part + bias[j]   (i < Da, j < Db): the two-operand product's epilogue.
 // One thread per output element (a single tile may be split 512 ways: 64 MB of slabs), slabs summed
 // in a fixed order.
-__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const double* part, int ntb, int ntl, int ksplit, int Da,
+__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const double* part, int ntb, int ntl, int nsub, int Da,
                                                         int Db, double alpha, const double* bias, double* C,
                                                         int64_t ldc) {
     const int t = blockIdx.y, ti = t / ntb, tj = t - ti * ntb;
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int i = ti * kT + e / kT, j = tj * kT + e % kT;
     if (i >= Da || j >= Db) return;
-    const double* p = part + (int64_t)t * (kT * kT) + e;
-    const int64_t stride = (int64_t)ntl * (kT * kT);
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int k = 0;
-    for (; k + 4 <= ksplit; k += 4) {
-        s0 += p[(k + 0) * stride];
-        s1 += p[(k + 1) * stride];
-        s2 += p[(k + 2) * stride];
-        s3 += p[(k + 3) * stride];
+    // one class of ntl tiles (SyrkPlan): slabs x + 8 (k ntl + t), sub-range k, XCD x
+    double sx[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) sx[x] = 0.0;
+    for (int k = 0; k < nsub; ++k) {
+        const double* p = part + (int64_t)(8 * (k * ntl + t)) * (kT * kT) + e;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) sx[x] += p[(int64_t)x * (kT * kT)];
     }
-    for (; k < ksplit; ++k) s0 += p[k * stride];
-    double s = alpha * ((s0 + s1) + (s2 + s3));
+    double s = alpha * (((sx[0] + sx[1]) + (sx[2] + sx[3])) + ((sx[4] + sx[5]) + (sx[6] + sx[7])));
     if (bias) s += bias[j];
     C[(int64_t)i * ldc + j] = s;
 }
@@ -708,20 +802,83 @@ int vt_large_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, co
     return vt_launch_status();
 }
 
-// Split of the N axis: one 512-thread workgroup per CU at a time, so pick the split whose grid
-// (ntl * ks workgroups) fills whole rounds of the chip best.
-static int syrk_split(int ntl, int ks_max = 64) {
-    const int cu = num_cu() * (large_stages() == 2 ? 2 : 1);   // workgroups resident at a time
-    int best = 1;
-    double best_eff = 0.0;
-    for (int ks = 1; ks <= ks_max; ++ks) {
-        const int64_t wgs = (int64_t)ntl * ks;
-        const int64_t rounds = (wgs + cu - 1) / cu;
-        double eff = (double)wgs / (double)(rounds * cu);
-        if (rounds < 2) eff *= 0.9;          // a single round has no tail to hide the ramp
-        if (eff > best_eff + 1e-9) {
-            best_eff = eff;
-            best = ks;
+static SyrkPlan uniform_plan(int ntl, int nsub) {   // one class: every tile splits each XCD's rows nsub ways
+    SyrkPlan p{};
+    p.n[0] = ntl;
+    for (int c = 0; c < 4; ++c) p.s[c] = nsub;
+    p.off[1] = p.off[2] = p.off[3] = p.per_xcd = ntl * nsub;
+    return p;
+}
+
+// SYRK: at most `rounds` rounds of an XCD's 64 resident workgroups (32 CUs x 2), dealt to the tile classes in
+// proportion to n_c cost_c.  The launch must FIT whole rounds -- one workgroup too many starts another round, as
+// long as the first -- so shares are rounded down and the class with the most work per workgroup then gets one
+// more sub-range per tile while the whole still fits.
+static SyrkPlan syrk_plan_for(int D, int64_t N, int target, int& maxper_out, const int (&cost)[4]) {
+    const int nt = (D + kT - 1) / kT, wl = D - (nt - 1) * kT;
+    const bool partial = wl < kT;
+    const int nfull = partial ? nt - 1 : nt;
+    SyrkPlan p{};
+    p.n[0] = nfull * (nfull - 1) / 2;
+    p.n[1] = nfull;
+    p.n[2] = partial ? nt - 1 : 0;
+    p.n[3] = partial ? 1 : 0;
+    double W = 0.0;
+    for (int c = 0; c < 4; ++c) W += (double)p.n[c] * cost[c];
+    const int64_t max_sub = std::max<int64_t>(1, (N / 8 + 4 * kKC - 1) / (4 * kKC));   // at least 4 stages per workgroup
+    int wg = 0;
+    for (int c = 0; c < 4; ++c) {
+        p.s[c] = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)(target * (double)cost[c] / W), max_sub));
+        wg += p.n[c] * p.s[c];
+    }
+    while (true) {
+        int best = -1;
+        double worst = 0.0, heaviest = 0.0;
+        for (int c = 0; c < 4; ++c) {
+            if (p.n[c] == 0) continue;
+            const double per_wg = (double)cost[c] / p.s[c];
+            heaviest = std::max(heaviest, per_wg);
+            if (p.s[c] >= max_sub || wg + p.n[c] > target) continue;
+            if (per_wg > worst) {
+                worst = per_wg;
+                best = c;
+            }
+        }
+        if (best < 0 || worst < heaviest) break;   // (only while it shortens the launch)
+        p.s[best] += 1;
+        wg += p.n[best];
+    }
+    wg = 0;
+    double maxper = 0.0;
+    for (int c = 0; c < 4; ++c) {
+        p.off[c] = wg;
+        wg += p.n[c] * p.s[c];
+        if (p.n[c] > 0) maxper = std::max(maxper, 1000.0 * cost[c] / p.s[c]);
+    }
+    p.per_xcd = wg;
+    maxper_out = (int)maxper;
+    return p;
+}
+constexpr int kSyrkMaxRounds = 2;
+static SyrkPlan syrk_plan(int D, int64_t N) {
+    static const int rounds_env = getenv("VT_SYRK_ROUNDS") ? atoi(getenv("VT_SYRK_ROUNDS")) : 0;   // dev switch
+    const int nt = (D + kT - 1) / kT, wl = D - (nt - 1) * kT;
+    const int cost[4] = {syrk_tile_cost(false, kT, kT), syrk_tile_cost(true, kT, kT), syrk_tile_cost(false, wl, kT),
+                         syrk_tile_cost(true, wl, wl)};
+    const int slots = 2 * num_cu() / 8;
+    SyrkPlan best{};
+    double best_est = 0.0;
+    for (int r = 1; r <= kSyrkMaxRounds; ++r) {
+        if (rounds_env > 0 && r != std::min(rounds_env, kSyrkMaxRounds)) continue;
+        int maxper;
+        const SyrkPlan p = syrk_plan_for(D, N, r * slots, maxper, cost);
+        double W = 0.0;
+        for (int c = 0; c < 4; ++c) W += 1000.0 * p.n[c] * cost[c];
+        // one round: as long as its heaviest workgroup; more: the mean load of a slot plus half a workgroup of tail
+        const double est = p.per_xcd <= slots ? (double)maxper : W / slots + 0.5 * maxper;
+        if (best.per_xcd == 0 || est < best_est) {
+            best = p;
+            best_est = est;
         }
     }
     return best;
@@ -729,31 +886,30 @@ static int syrk_split(int ntl, int ks_max = 64) {
 
 size_t vt_large_syrk_ws_bytes(int D) {
     const int nt = (D + kT - 1) / kT, ntl = nt * (nt + 1) / 2;
-    return (size_t)syrk_split(ntl) * ntl * kT * kT * sizeof(double);
+    // a plan fits kSyrkMaxRounds rounds of the chip unless every tile is already unsplit
+    return (size_t)std::max(kSyrkMaxRounds * 2 * num_cu(), 8 * ntl) * kT * kT * sizeof(double);
 }
 
 int vt_large_syrk(const double* X, int64_t ldx, const double* d, int64_t N, int D, const double* prior, double* H,
                   int ldh, void* ws, hipStream_t st) {
     const int nt = (D + kT - 1) / kT, ntl = nt * (nt + 1) / 2;
-    int ks = syrk_split(ntl);
-    int64_t nsteps = (N + 3) / 4;
-    if (ks > nsteps) ks = (int)std::max<int64_t>(1, nsteps);
-    SyrkArgs a{X, ldx, d, N, D, nt, ks, (double*)ws, nullptr, 0, 0, 0};
+    SyrkPlan plan = syrk_plan(D, N);
+    SyrkArgs a{X, ldx, d, N, D, nt, plan, (double*)ws, nullptr, 0, 0, 0};
     if (N == 0) {
-        ks = 0;   // no rows: the reduce below sums zero slabs and adds the prior
+        for (int c = 0; c < 4; ++c) plan.s[c] = 0;   // no rows: the reduce below sums zero slabs and adds the prior
     } else if (ldx % 2 == 0 && (uintptr_t)X % 16 == 0 && !large_no_lds()) {
         const size_t shmem = (size_t)large_stages() * 2 * kKC * (kT + 16) * sizeof(double);   // 108 / 72 KB
         static VtLdsAttr attr[2];
         if (vt_allow_big_lds((const void*)k_syrk_lds<false, 3>, attr[0], (int)shmem) != VT_OK ||
             vt_allow_big_lds((const void*)k_syrk_lds<false, 2>, attr[1], (int)shmem) != VT_OK)
             return VT_ERR_HIP;
-        if (large_stages() == 2) hipLaunchKernelGGL((k_syrk_lds<false, 2>), dim3(ntl, ks), dim3(512), shmem, st, a);
-        else hipLaunchKernelGGL((k_syrk_lds<false, 3>), dim3(ntl, ks), dim3(512), shmem, st, a);
+        if (large_stages() == 2) hipLaunchKernelGGL((k_syrk_lds<false, 2>), dim3(8 * plan.per_xcd), dim3(512), shmem, st, a);
+        else hipLaunchKernelGGL((k_syrk_lds<false, 3>), dim3(8 * plan.per_xcd), dim3(512), shmem, st, a);
     } else {
-        hipLaunchKernelGGL(k_syrk_tile<false>, dim3(ntl, ks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_syrk_tile<false>, dim3(8 * plan.per_xcd), dim3(256), 0, st, a);
     }
-    hipLaunchKernelGGL(k_syrk_reduce, dim3(kT * kT / 256, ntl), dim3(256), 0, st, (const double*)ws, nt, ks, D, prior, H,
-                       ldh);
+    hipLaunchKernelGGL(k_syrk_reduce, dim3(kT * kT / 256, ntl), dim3(256), 0, st, (const double*)ws, nt, plan, D, prior,
+                       H, ldh);
     return vt_launch_status();
 }
 
@@ -761,15 +917,13 @@ int vt_large_syrk(const double* X, int64_t ldx, const double* d, int64_t N, int 
 // C (Da x Db) = alpha * A^T diag(s) B + 1 bias^T for row-major A (N x Da), B (N x Db): the SYRK
 // kernels with a second operand and a rectangular tile grid; the N axis is split so that the
 // grid fills the chip even when there is a single output tile.
-static int gemm_tn_split(int ntl) {
-    const int cu = num_cu();
-    return syrk_split(ntl, std::max(1, std::min(512, 2 * cu / ntl)));
-}
+// (sub-ranges of an XCD's rows per tile: one round of the XCD's 64 resident workgroups when the tiles are fewer)
+static int gemm_tn_split(int ntl) { return std::max(1, (2 * num_cu() / 8) / ntl); }
 
 extern "C" size_t vt_gemm_tn_workspace_bytes(int Da, int Db) {
     if (Da < 1 || Db < 1 || Da > VT_DENSE_D_MAX || Db > VT_DENSE_D_MAX) return 0;
     const int nta = (Da + kT - 1) / kT, ntb = (Db + kT - 1) / kT;
-    return (size_t)gemm_tn_split(nta * ntb) * nta * ntb * kT * kT * sizeof(double);
+    return (size_t)8 * gemm_tn_split(nta * ntb) * nta * ntb * kT * kT * sizeof(double);
 }
 
 template <typename BT>
@@ -782,10 +936,10 @@ static int gemm_tn_impl(const double* A, int64_t lda, int Da, const BT* B, int64
     if (!ws || ws_bytes < vt_gemm_tn_workspace_bytes(Da, Db)) return VT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int nta = (Da + kT - 1) / kT, ntb = (Db + kT - 1) / kT, ntl = nta * ntb;
-    int ks = gemm_tn_split(ntl);
-    const int64_t nsteps = (N + kKC - 1) / kKC;
+    int ks = gemm_tn_split(ntl);   // sub-ranges per XCD
+    const int64_t nsteps = (N / 8 + 4 * kKC - 1) / (4 * kKC);   // at least 4 stages per workgroup
     if (ks > nsteps) ks = (int)std::max<int64_t>(1, nsteps);
-    SyrkArgs a{A, lda, rowscale, N, Da, nta, ks, (double*)ws, B, ldb, Db, ntb};
+    SyrkArgs a{A, lda, rowscale, N, Da, nta, uniform_plan(ntl, ks), (double*)ws, B, ldb, Db, ntb};
     constexpr int kBPer16 = 16 / (int)sizeof(BT);   // B elements per 16-byte DMA lane
     if (N == 0) {
         ks = 0;   // no rows: C = bias
@@ -795,10 +949,10 @@ static int gemm_tn_impl(const double* A, int64_t lda, int Da, const BT* B, int64
         if (vt_allow_big_lds((const void*)k_syrk_lds<true, 3, BT>, attr[0], (int)shmem) != VT_OK ||
             vt_allow_big_lds((const void*)k_syrk_lds<true, 2, BT>, attr[1], (int)shmem) != VT_OK)
             return VT_ERR_HIP;
-        if (large_stages() == 2) hipLaunchKernelGGL((k_syrk_lds<true, 2, BT>), dim3(ntl, ks), dim3(512), shmem, st, a);
-        else hipLaunchKernelGGL((k_syrk_lds<true, 3, BT>), dim3(ntl, ks), dim3(512), shmem, st, a);
+        if (large_stages() == 2) hipLaunchKernelGGL((k_syrk_lds<true, 2, BT>), dim3(8 * ntl * ks), dim3(512), shmem, st, a);
+        else hipLaunchKernelGGL((k_syrk_lds<true, 3, BT>), dim3(8 * ntl * ks), dim3(512), shmem, st, a);
     } else {
-        hipLaunchKernelGGL((k_syrk_tile<true, BT>), dim3(ntl, ks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_syrk_tile<true, BT>), dim3(8 * ntl * ks), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3(kT * kT / 256, ntl), dim3(256), 0, st, (const double*)ws, ntb, ntl, ks,
                        Da, Db, alpha, bias, C, ldc);
