@@ -162,6 +162,19 @@ int    vt_glm_hvp(const double* X_dev, int64_t ldx, const double* d_dev, const d
                   double prior_scalar, const double* v_dev, int64_t N, int D, double* out_dev,
                   void* ws_dev, size_t ws_bytes, void* stream);
 
+/* K6 for K vectors at once: Out[k, :] = X^T (d .* (X V[k, :])) + prior .* V[k, :]  (V, Out: K x D, one vector per
+ * row, K <= 128): two passes of the MFMA tile kernels over X (Z = X V^T, then Z^T diag(d) X) -- 16 N D bytes for
+ * the K products where K calls of vt_glm_hvp read 8 K N D.  Needs ldx even and X 16-byte aligned for the LDS-staged
+ * kernels (other layouts take the direct-from-global kernels).
+ * Replaces: the `mat_times_vec` of get_cg_solver applied to EVERY column of the cross-Hessian
+ *             vittles/solver_lib.py:91-97 under vittles/sensitivity_lib.py:226 (`self._hess_solver(jac0)` with a
+ *             (D, N) jac0: SciPy's cg takes one right-hand side, so the reference's CG route cannot run it; the
+ *             block solver here is the build-side extension SURVEY.md section 3.3 names). */
+size_t vt_glm_hvp_multi_workspace_bytes(int64_t N, int D, int K);
+int    vt_glm_hvp_multi(const double* X_dev, int64_t ldx, const double* d_dev, const double* prior_dev,
+                        double prior_scalar, const double* V_dev, int64_t ldv, int K, int64_t N, int D,
+                        double* Out_dev, int64_t ldo, void* ws_dev, size_t ws_bytes, void* stream);
+
 /* vt_glm_hvp without a workspace argument, for callers that cannot allocate.
  * No counterpart in the reference: this entry point exists for callers that must not call hipMalloc
  * (code under HIP graph capture, tight serving loops around the CG iteration, harnesses that forbid
@@ -311,6 +324,17 @@ int    vt_cg_init(const double* b_dev, const double* q0_dev, double* r_dev, doub
                   double* scal_dev, void* stream);
 int    vt_cg_update(double* p_dev, const double* q_dev, double* x_dev, double* r_dev, int64_t D,
                     double* scal_dev, void* stream);
+/* The same for K right-hand sides in lock-step (independent recurrences: column k of every array at offset k*ld)
+ * with an optional DIAGONAL preconditioner minv_dev (D,) -- SciPy's `M` (cg_opts of vittles/solver_lib.py:93):
+ * z = minv .* r, rho = r.z, p = z + (rho/rho_prev) p, stopping test on ||r||.
+ * scal_dev: 8 doubles per column: [0] rho, [1] ||r||, [2] alpha, [3] p.q, [4] ||b||, [5] iterations done,
+ * [6] atol, written by the host after the init: a column with ||r|| < atol is frozen (not updated, not counted).
+ * Replaces: scipy.sparse.linalg.cg run once per column of the right-hand side (vittles/solver_lib.py:91-97 under
+ *             vittles/sensitivity_lib.py:226). */
+int    vt_cg_init_multi(const double* b_dev, const double* q0_dev, double* r_dev, double* p_dev, int64_t D,
+                        int64_t ld, int K, const double* minv_dev, double* scal_dev, void* stream);
+int    vt_cg_update_multi(double* p_dev, const double* q_dev, double* x_dev, double* r_dev, int64_t D,
+                          int64_t ld, int K, const double* minv_dev, double* scal_dev, void* stream);
 
 /* out_dev[0] = sum_i a_i b_i c_i  (c_dev NULL: sum_i a_i b_i), one workgroup, fixed summation order.
  * Replaces: the NumPy reductions around the path -- np.linalg.norm of the estimating equation / of the Newton

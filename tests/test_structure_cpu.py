@@ -85,3 +85,60 @@ def test_not_arrowhead_and_explicit_keywords():
         shl.detect_arrowhead(sp.identity(4, format="csr"), sparsity_array=np.array([[0, 1], [1, 2]]))
     with pytest.raises(ValueError, match="must be disjoint"):
         shl.detect_arrowhead(sp.identity(4, format="csr"), sparsity_array=np.array([[0, 1]]), global_inds=[1, 2])
+
+
+def _arrow(rng, G=40, M=4, Kg=2):
+    d = G * M + Kg
+    A = np.zeros((d, d))
+    for g in range(G):
+        A[g * M:(g + 1) * M, g * M:(g + 1) * M] = _spd(rng, M)
+    A[:G * M, G * M:] = rng.standard_normal((G * M, Kg))
+    A[G * M:, :G * M] = A[:G * M, G * M:].T
+    A[G * M:, G * M:] = _spd(rng, Kg) + G
+    return A
+
+
+def test_one_triangle_or_non_symmetric_input_is_refused():
+    """the structured solve reads (local row, global col) entries only; an input that stores one
+    triangle, or is not symmetric, must raise instead of silently solving another matrix (the reference's LU,
+    vittles/solver_lib.py:48, would have taken it)."""
+    from vittles_amd import sparse_hessian_lib as shl
+    rng = np.random.default_rng(3)
+    A = _arrow(rng)
+    d = A.shape[0]
+    inds = np.arange(40 * 4).reshape(40, 4)
+    with pytest.raises(ValueError, match="SYMMETRIC"):
+        shl.arrowhead_from_sparse(sp.csc_matrix(np.triu(A)), sparsity_array=inds)
+    with pytest.raises(ValueError, match="SYMMETRIC"):
+        shl.arrowhead_from_sparse(sp.csc_matrix(np.tril(A)), sparsity_array=inds)
+    B = A.copy()
+    B[3, d - 1] *= 1.001                         # border entry without its mirror image
+    with pytest.raises(ValueError, match="border"):
+        shl.arrowhead_from_sparse(sp.coo_matrix(B), sparsity_array=inds)
+    C = A.copy()
+    C[1, 2] += 0.5                               # inside a block
+    with pytest.raises(ValueError, match="block diagonal"):
+        shl.arrowhead_from_sparse(sp.coo_matrix(C), sparsity_array=inds)
+    E = A.copy()
+    E[d - 1, d - 2] += 0.5                       # inside the corner
+    with pytest.raises(ValueError, match="corner"):
+        shl.arrowhead_from_sparse(sp.coo_matrix(E), sparsity_array=inds)
+
+
+def test_fingerprint_sees_swapped_and_moved_entries():
+    """in-place edits that keep nnz and the sums must still change the fingerprint."""
+    from vittles_amd import sparse_hessian_lib as shl
+    rng = np.random.default_rng(4)
+    h = sp.coo_matrix(_arrow(rng))
+    f0 = shl.matrix_fingerprint(h)
+    assert f0 == shl.matrix_fingerprint(h.copy())
+    g = h.copy()
+    g.data[[0, 5]] = g.data[[5, 0]]              # swapped values: same sum, same abs-sum
+    assert shl.matrix_fingerprint(g) != f0
+    g = h.copy()
+    g.row[[0, 700]] = g.row[[700, 0]]            # moved entries: values untouched
+    assert shl.matrix_fingerprint(g) != f0
+    c = h.tocsc()
+    fc = shl.matrix_fingerprint(c)
+    c.indices[:2] = c.indices[:2][::-1].copy()
+    assert shl.matrix_fingerprint(c) != fc

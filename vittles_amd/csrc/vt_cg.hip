@@ -79,6 +79,100 @@ __global__ __launch_bounds__(1024) void k_cg_init(const double* b, const double*
 
 }  // namespace
 
+namespace {
+// ---- K columns in lock-step (block CG with independent recurrences), optional diagonal preconditioner ----------
+// Column k lives at offset k * ld of every vector array; scal holds 8 doubles per column:
+//   [0] rho = r.z   [1] ||r||   [2] alpha   [3] p.q   [4] ||b||   [5] iterations done   [6] atol (set by the host
+//   after the init: the column is FROZEN -- neither updated nor counted -- once ||r|| < atol)   [7] unused
+// minv (D,) or NULL: z = minv .* r is SciPy's `M @ r` for a diagonal M ~ A^{-1} (scipy.sparse.linalg.cg's loop:
+// z = psolve(r); rho = r.z; p = z + (rho/rho_prev) p; the stopping test stays on ||r||).
+__global__ __launch_bounds__(1024) void k_cg_update_multi(double* P, const double* Q, double* Xs, double* R, int64_t D,
+                                                          int64_t ld, const double* minv, double* scal_all) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    double* scal = scal_all + 8 * blockIdx.x;
+    if (scal[1] < scal[6]) return;   // converged column (uniform over the workgroup)
+    double* p = P + blockIdx.x * ld;
+    const double* q = Q + blockIdx.x * ld;
+    double* x = Xs + blockIdx.x * ld;
+    double* r = R + blockIdx.x * ld;
+    double pq = 0.0;
+    for (int64_t i = tid; i < D; i += 1024) pq = fma(p[i], q[i], pq);
+    pq = block_sum(pq, red);
+    const double rho = scal[0];
+    const double alpha = rho / pq;
+    double rr = 0.0, rz = 0.0;
+    for (int64_t i = tid; i < D; i += 1024) {
+        x[i] = fma(alpha, p[i], x[i]);
+        double ri = fma(-alpha, q[i], r[i]);
+        r[i] = ri;
+        rr = fma(ri, ri, rr);
+        if (minv) rz = fma(ri * minv[i], ri, rz);
+    }
+    rr = block_sum(rr, red);
+    if (minv) rz = block_sum(rz, red);
+    else rz = rr;
+    const double beta = rz / rho;
+    for (int64_t i = tid; i < D; i += 1024) p[i] = fma(beta, p[i], minv ? minv[i] * r[i] : r[i]);
+    if (tid == 0) {
+        scal[0] = rz;
+        scal[1] = sqrt(rr);
+        scal[2] = alpha;
+        scal[3] = pq;
+        scal[5] += 1.0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_cg_init_multi(const double* B, const double* Q0, double* R, double* P,
+                                                        int64_t D, int64_t ld, const double* minv, double* scal_all) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    double* scal = scal_all + 8 * blockIdx.x;
+    const double* b = B + blockIdx.x * ld;
+    const double* q0 = Q0 ? Q0 + blockIdx.x * ld : nullptr;
+    double* r = R + blockIdx.x * ld;
+    double* p = P + blockIdx.x * ld;
+    double rr = 0.0, bb = 0.0, rz = 0.0;
+    for (int64_t i = tid; i < D; i += 1024) {
+        double bi = b[i];
+        double ri = q0 ? bi - q0[i] : bi;
+        double zi = minv ? minv[i] * ri : ri;
+        r[i] = ri;
+        p[i] = zi;
+        rr = fma(ri, ri, rr);
+        rz = fma(ri, zi, rz);
+        bb = fma(bi, bi, bb);
+    }
+    rr = block_sum(rr, red);
+    rz = block_sum(rz, red);
+    bb = block_sum(bb, red);
+    if (tid == 0) {
+        scal[0] = rz;
+        scal[1] = sqrt(rr);
+        scal[2] = 0.0;
+        scal[3] = 0.0;
+        scal[4] = sqrt(bb);
+        scal[5] = 0.0;
+        scal[6] = 0.0;
+        scal[7] = 0.0;
+    }
+}
+}  // namespace
+
+extern "C" int vt_cg_init_multi(const double* b, const double* q0, double* r, double* p, int64_t D, int64_t ld, int K,
+                                const double* minv, double* scal, void* stream) {
+    if (!b || !r || !p || !scal || D < 1 || K < 1 || (K > 1 && ld < D)) return VT_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_cg_init_multi, dim3(K), dim3(1024), 0, (hipStream_t)stream, b, q0, r, p, D, ld, minv, scal);
+    return vt_launch_status();
+}
+
+extern "C" int vt_cg_update_multi(double* p, const double* q, double* x, double* r, int64_t D, int64_t ld, int K,
+                                  const double* minv, double* scal, void* stream) {
+    if (!p || !q || !x || !r || !scal || D < 1 || K < 1 || (K > 1 && ld < D)) return VT_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_cg_update_multi, dim3(K), dim3(1024), 0, (hipStream_t)stream, p, q, x, r, D, ld, minv, scal);
+    return vt_launch_status();
+}
+
 extern "C" int vt_cg_init(const double* b, const double* q0, double* r, double* p, int64_t D, double* scal,
                           void* stream) {
     if (!b || !r || !p || !scal || D < 1) return VT_ERR_BAD_ARG;

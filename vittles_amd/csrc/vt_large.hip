@@ -920,20 +920,24 @@ int vt_large_syrk(const double* X, int64_t ldx, const double* d, int64_t N, int 
 // (sub-ranges of an XCD's rows per tile: one round of the XCD's 64 resident workgroups when the tiles are fewer)
 static int gemm_tn_split(int ntl) { return std::max(1, (2 * num_cu() / 8) / ntl); }
 
-extern "C" size_t vt_gemm_tn_workspace_bytes(int Da, int Db) {
-    if (Da < 1 || Db < 1 || Da > VT_DENSE_D_MAX || Db > VT_DENSE_D_MAX) return 0;
+static size_t gemm_tn_ws_bytes(int Da, int Db) {
     const int nta = (Da + kT - 1) / kT, ntb = (Db + kT - 1) / kT;
     return (size_t)8 * gemm_tn_split(nta * ntb) * nta * ntb * kT * kT * sizeof(double);
+}
+
+extern "C" size_t vt_gemm_tn_workspace_bytes(int Da, int Db) {
+    if (Da < 1 || Db < 1 || Da > VT_DENSE_D_MAX || Db > VT_DENSE_D_MAX) return 0;
+    return gemm_tn_ws_bytes(Da, Db);
 }
 
 template <typename BT>
 static int gemm_tn_impl(const double* A, int64_t lda, int Da, const BT* B, int64_t ldb, int Db, const double* rowscale,
                         int64_t N, double alpha, const double* bias, double* C, int64_t ldc, void* ws, size_t ws_bytes,
-                        void* stream) {
+                        void* stream, int db_max = VT_DENSE_D_MAX) {
     if (!C || N < 0 || Da < 1 || Db < 1 || lda < Da || ldb < Db || ldc < Db) return VT_ERR_BAD_ARG;
     if (N > 0 && (!A || !B)) return VT_ERR_BAD_ARG;
-    if (Da > VT_DENSE_D_MAX || Db > VT_DENSE_D_MAX) return VT_ERR_UNSUPPORTED;
-    if (!ws || ws_bytes < vt_gemm_tn_workspace_bytes(Da, Db)) return VT_ERR_WORKSPACE;
+    if (Da > VT_DENSE_D_MAX || Db > db_max) return VT_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < gemm_tn_ws_bytes(Da, Db)) return VT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int nta = (Da + kT - 1) / kT, ntb = (Db + kT - 1) / kT, ntl = nta * ntb;
     int ks = gemm_tn_split(ntl);   // sub-ranges per XCD
@@ -970,4 +974,52 @@ extern "C" int vt_gemm_tn_f32b(const double* A, int64_t lda, int Da, const float
                                const double* rowscale, int64_t N, double alpha, const double* bias, double* C,
                                int64_t ldc, void* ws, size_t ws_bytes, void* stream) {
     return gemm_tn_impl<float>(A, lda, Da, B, ldb, Db, rowscale, N, alpha, bias, C, ldc, ws, ws_bytes, stream);
+}
+
+// ------------------------------------------------------------------ multi-vector HVP -------
+// Out[k, :] = X^T (d .* (X V[k, :])) + prior .* V[k, :]  for K vectors at once (V, Out: K x D, one vector per row).
+// The single-vector kernel (vt_rows.hip) keeps v in LDS and the row in registers: K vectors do not fit either, so the
+// K products are two passes of the MFMA tile kernels over X -- Z (N x K) = X V^T (GEMM-NT, a remainder panel of K
+// columns: the narrow wave grid) and Out = Z^T diag(d) X (the two-operand product with a K-row first operand) --
+// 16 N D bytes for any K <= 128 where K single products read 8 K N D.  Build-side extension:
+// the reference applies its solver to all columns of the cross-Hessian at once (vittles/sensitivity_lib.py:226) and
+// its CG route (vittles/solver_lib.py:91-97) would call the HVP once per column and iteration.
+namespace {
+__global__ void k_add_prior_rows(const double* prior, double prior_scalar, const double* V, int64_t ldv, int K, int D,
+                                 double* Out, int64_t ldo) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)K * D) return;
+    const int k = (int)(idx / D), j = (int)(idx - (int64_t)k * D);
+    const double pj = prior ? prior[j] : prior_scalar;
+    Out[k * ldo + j] = fma(pj, V[k * ldv + j], Out[k * ldo + j]);
+}
+inline int hvp_multi_kp(int K) { return (K + 1) & ~1; }   // Z rows on a 16-byte pitch
+}  // namespace
+
+extern "C" size_t vt_glm_hvp_multi_workspace_bytes(int64_t N, int D, int K) {
+    if (N < 0 || D < 1 || K < 1 || K > kT || D > VT_ROWS_D_MAX) return 0;
+    return ((size_t)N * hvp_multi_kp(K) * sizeof(double) + 255) / 256 * 256 + gemm_tn_ws_bytes(K, D);
+}
+
+extern "C" int vt_glm_hvp_multi(const double* X, int64_t ldx, const double* d, const double* prior, double prior_scalar,
+                                const double* V, int64_t ldv, int K, int64_t N, int D, double* Out, int64_t ldo,
+                                void* ws, size_t ws_bytes, void* stream) {
+    if (!V || !Out || N < 0 || D < 1 || K < 1 || ldx < D || ldv < D || ldo < D) return VT_ERR_BAD_ARG;
+    if (N > 0 && (!X || !d)) return VT_ERR_BAD_ARG;
+    if (K > kT || D > VT_ROWS_D_MAX) return VT_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < vt_glm_hvp_multi_workspace_bytes(N, D, K)) return VT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int Kp = hvp_multi_kp(K);
+    double* Z = (double*)ws;
+    void* tn_ws = (char*)ws + ((size_t)N * Kp * sizeof(double) + 255) / 256 * 256;
+    if (Kp > K && N > 0) VT_CHECK_HIP(hipMemsetAsync(Z, 0, (size_t)N * Kp * sizeof(double), st));   // the pad column
+    int rc = gemm_nt(Z, Kp, N, K, X, ldx, V, ldv, D, 1.0, 0.0, false, st);
+    if (rc != VT_OK) return rc;
+    rc = gemm_tn_impl<double>(Z, Kp, K, X, ldx, D, d, N, 1.0, nullptr, Out, ldo, tn_ws, gemm_tn_ws_bytes(K, D), stream,
+                              VT_ROWS_D_MAX);
+    if (rc != VT_OK) return rc;
+    const int64_t tot = (int64_t)K * D;
+    hipLaunchKernelGGL(k_add_prior_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, prior, prior_scalar, V, ldv,
+                       K, D, Out, ldo);
+    return vt_launch_status();
 }

@@ -6,17 +6,23 @@ from . import _lib, device as dev
 _ws_cache = {}
 
 
-def _workspace(D, device):
-    """Scratch of the row-streaming kernels, one buffer per (device, STREAM, size): two streams of one process
-    never share scratch (kernels on different streams may overlap)."""
-    lib = dev.require_gpu()
-    nbytes = lib.vt_rows_workspace_bytes(int(D))
-    key = (device.index, dev.stream_ptr(), nbytes)
-    ws = _ws_cache.get(key)
-    if ws is None:
+def _grow_only(cache, device, nbytes):
+    """One buffer per (device, STREAM), reallocated only when a call needs more: two streams of one process never
+    share scratch (kernels on different streams may overlap), and a sweep over D does not pin a buffer per size."""
+    key = (device.index, dev.stream_ptr())
+    ws = cache.get(key)
+    if ws is None or ws.numel() * 8 < nbytes:
         ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
-        _ws_cache[key] = ws
+        cache[key] = ws
     return ws
+
+
+def _workspace(D, device):
+    """Scratch of the row-streaming kernels (sized for the CU count of ``device``, not of the current device)."""
+    lib = dev.require_gpu()
+    with torch.cuda.device(device):
+        nbytes = lib.vt_rows_workspace_bytes(int(D))
+    return _grow_only(_ws_cache, device, nbytes)
 
 
 def dot(a, b, c=None):
@@ -194,6 +200,32 @@ def glm_hvp(X, d, v, prior=None, prior_scalar=0.0, out=None):
     _lib.check(_lib.fn(lib, "vt_glm_hvp", X)(X.data_ptr(), dev.ld(X), d.data_ptr(), dev.ptr(prior), float(prior_scalar),
                               v.data_ptr(), N, D, out.data_ptr(), ws.data_ptr(), ws.numel() * 8,
                               dev.stream_ptr()), "vt_glm_hvp")
+    return out
+
+
+_hvp_multi_ws_cache = {}
+
+
+def glm_hvp_multi(X, d, V, prior=None, prior_scalar=0.0, out=None):
+    """K6 for K vectors at once: out[k, :] = X^T (d .* (X V[k, :])) + prior .* V[k, :] for row-major CUDA fp64
+    ``V`` (K, D), K <= 128 -- X is read twice whatever K is (csrc/vt_large.hip: vt_glm_hvp_multi)."""
+    lib = dev.require_gpu()
+    _fp64_only(X, "glm_hvp_multi")
+    N, D = X.shape
+    V = _rowmajor(V)
+    K = V.shape[0]
+    if V.shape[1] != D:
+        raise ValueError("V must be (K, %d)" % D)
+    if out is None:
+        out = torch.empty((K, D), dtype=torch.float64, device=X.device)
+    with torch.cuda.device(X.device):
+        nbytes = lib.vt_glm_hvp_multi_workspace_bytes(N, D, K)
+    if nbytes == 0:
+        raise _lib.VittlesHipError("vt_glm_hvp_multi takes 1 <= K <= 128 vectors (got %d) of D <= 20448" % K)
+    ws = _grow_only(_hvp_multi_ws_cache, X.device, nbytes)
+    _lib.check(lib.vt_glm_hvp_multi(X.data_ptr(), dev.ld(X), d.data_ptr(), dev.ptr(prior), float(prior_scalar),
+                                    V.data_ptr(), dev.ld(V), K, N, D, out.data_ptr(), dev.ld(out), ws.data_ptr(),
+                                    ws.numel() * 8, dev.stream_ptr()), "vt_glm_hvp_multi")
     return out
 
 

@@ -73,7 +73,9 @@ def get_sparse_cholesky_solver(h, sparsity_array=None, global_inds=None):
             'get_sparse_cholesky_solver: the %d x %d matrix is not block-arrowhead (blocks and border of at most '
             '%d) and is too large for the dense device Cholesky (%d); pass sparsity_array= / global_inds= if the '
             'pattern alone does not show the structure.' % (d, d, shl.MAX_BLOCK, DENSE_D_MAX))
-    return get_dense_cholesky_solver(np.asarray(h.todense()))
+    hd = np.asarray(h.todense())
+    shl._require_symmetric(hd, hd.T, 'matrix')      # the dense Cholesky reads one triangle only
+    return get_dense_cholesky_solver(hd)
 
 
 def get_cholesky_solver(h):

@@ -205,10 +205,29 @@ def _triplets_to_host(vals, rows, cols, d):
 
 
 def matrix_fingerprint(mat):
-    """Cheap check that a scipy sparse matrix still holds the values a device-side structure snapshot was
-    taken from (an in-place edit of ``.data`` keeps Python attributes alive): shape, nnz and two sums."""
-    data = np.asarray(mat.data, dtype=np.float64)
-    return (tuple(mat.shape), int(mat.nnz), float(data.sum()), float(np.abs(data).sum()))
+    """Check that a scipy sparse matrix still holds the content a device-side structure snapshot was taken from
+    (an in-place edit of ``.data`` or of the index arrays keeps Python attributes alive): shape, nnz and a CRC of
+    the values AND the index arrays -- O(nnz), and unlike sums it sees entries that were swapped or moved."""
+    import zlib
+    crc = zlib.crc32(np.ascontiguousarray(mat.data).tobytes())
+    for name in ("row", "col", "indices", "indptr"):
+        arr = getattr(mat, name, None)
+        if arr is not None:
+            crc = zlib.crc32(np.ascontiguousarray(arr).tobytes(), crc)
+    return (tuple(mat.shape), int(mat.nnz), type(mat).__name__, crc)
+
+
+SYM_RTOL = 1e-12
+
+
+def _require_symmetric(a, b, what):
+    """``a`` must equal ``b`` (its mirror image) to rounding: the device solvers are Cholesky solvers and read one
+    triangle; the reference's SuperLU (vittles/solver_lib.py:48) would silently solve a different matrix."""
+    scale = max(float(np.abs(a).max(initial=0.0)), float(np.abs(b).max(initial=0.0)))
+    if scale > 0.0 and float(np.abs(a - b).max()) > SYM_RTOL * scale:
+        raise ValueError(
+            'get_sparse_cholesky_solver needs a SYMMETRIC (positive definite) matrix with both triangles stored; '
+            'the %s is not symmetric (max |h - h^T| = %.3g)' % (what, float(np.abs(a - b).max())))
 
 
 def _attach(mat, struct):
@@ -352,14 +371,20 @@ def arrowhead_from_sparse(h, device=None, sparsity_array=None, global_inds=None)
     if d_pad > d:                                # padding unknowns: unit diagonal, coupled to nothing
         padi = np.arange(d, d_pad)
         blocks[comp[padi], pos[padi], pos[padi]] = 1.0
+    _require_symmetric(blocks, blocks.transpose(0, 2, 1), 'block diagonal')
     border = corner = None
     if Kg > 0:
         border = np.zeros((G * M, Kg))
         lg = rl & ~cl
         np.add.at(border, (comp[r[lg]] * M + pos[r[lg]], pos[c[lg]]), v[lg])
+        mirror = np.zeros((G * M, Kg))           # the (global row, local column) entries: must mirror the border
+        gl = ~rl & cl
+        np.add.at(mirror, (comp[c[gl]] * M + pos[c[gl]], pos[r[gl]]), v[gl])
+        _require_symmetric(border, mirror, 'border (local x global against global x local entries)')
         corner = np.zeros((Kg, Kg))
         gg = ~rl & ~cl
         np.add.at(corner, (pos[r[gg]], pos[c[gg]]), v[gg])
+        _require_symmetric(corner, corner.T, 'global corner')
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device())
     to = lambda x: None if x is None else torch.as_tensor(x).to(device)
