@@ -273,3 +273,50 @@ def test_sparse_solver_stale_snapshot_and_fallbacks():
     Hneg.data = -Hneg.data
     with pytest.raises(np.linalg.LinAlgError):
         va.solver_lib.get_cholesky_solver(Hneg)(b)
+
+
+def test_config5_pipeline_launches_no_library_gemm(relerr):
+    """the config-5 pipeline (block Hessian -> LR covariances, also with more moments than one
+    vt_gemm_tn call takes) and the dense sensitivity path run under the kernel profiler: every device kernel is one
+    of this library's (k_*) or a torch copy / fill -- no rocBLAS / Tensile GEMM, no torch reduction kernel."""
+    import torch
+    import vittles_amd as va
+    from torch.profiler import profile, ProfilerActivity
+    G, ng, k = 40, 6, 3
+    m, obj = _model(G, ng, k, seed=5)
+    eta = m.optimum()
+    sb = va.SparseBlockHessian(obj, obj.sparsity_array())
+    rng = np.random.default_rng(0)
+    J = rng.standard_normal((12, m.d))
+    from oracle import glm
+    X, y, w, _ = glm.synth(3000, 40, "logistic", seed=2)
+    theta = glm.newton_optimum("logistic", X, y, w, prior=1.0)
+
+    def pipeline():
+        H = sb.get_hessian(eta)
+        lr = va.LinearResponseCovariances(obj, eta, validate_optimum=True, hessian_at_opt=H, grad_tol=1e-6)
+        cov = lr.get_lr_covariance_from_jacobians(J, J)
+        gobj = va.WeightedGLMObjective(X, y, family="logistic", prior=1.0)
+        sens = va.HyperparameterSensitivityLinearApproximation(gobj, torch.tensor(theta, device="cuda"),
+                                                               torch.tensor(w, device="cuda"), validate_optimum=True)
+        sens.predict_opt_par_from_hyper_par(torch.tensor(w * 1.01, device="cuda"))
+        return cov
+    pipeline()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        cov = pipeline()
+        torch.cuda.synchronize()
+    names = sorted({e.name for e in prof.events() if str(getattr(e, "device_type", "")).endswith("CUDA")})
+    if not names:
+        pytest.skip("the kernel profiler returned no device events on this box")
+    ours = lambda n: "(anonymous namespace)::k_" in n             # this library's kernels (csrc/*.hip)
+    bad = [n for n in names if not ours(n) and any(t in n.lower() for t in ("gemm", "gemv", "rocblas", "cijk", "tensile",
+                                                                             "reduce_kernel", "dot_kernel"))]
+    assert not bad, bad
+    assert sum(ours(n) for n in names) >= 8, names
+    Hc = np.asarray(sb.get_hessian(eta).todense())
+    assert relerr(cov, J @ np.linalg.solve(Hc, J.T)) < 1e-9
+    # more moments than one vt_gemm_tn call takes: column panels of 8192, still no library GEMM
+    from vittles_amd import rows
+    A = torch.tensor(rng.standard_normal((300, 8200)), device="cuda")
+    B = torch.tensor(rng.standard_normal((300, 5)), device="cuda")
+    assert relerr(rows.gemm_tn_tiled(A, B).cpu().numpy(), A.cpu().numpy().T @ B.cpu().numpy()) < 1e-10

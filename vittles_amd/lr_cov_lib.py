@@ -112,14 +112,13 @@ class LinearResponseCovariances:
             J1t = J1.t().contiguous()
             if sharding.group_rank(self._group) != 0 and self._n_global > 0:
                 J1t[J1t.shape[0] - self._n_global:] = 0.0
-            out = rows.gemm_tn(J1t, Z) if (1 <= K1 <= 8192 and 1 <= K2 <= 8192) else J1t.t() @ Z
+            out = rows.gemm_tn_tiled(J1t, Z)
             sharding.all_reduce_sum(out, self._group)
-        elif 1 <= K1 <= 8192 and 1 <= K2 <= 8192:
+        elif K1 >= 1 and K2 >= 1:
             J1t = J2t if same else J1.t().contiguous()                                   # (d, K1)
-            out = rows.gemm_tn(J1t, Z)
+            out = rows.gemm_tn_tiled(J1t, Z)      # (more than 8192 moments: panels of 8192, still vt_gemm_tn)
         else:
-            out = torch.stack([rows.gemv_t(Z, J1[i].contiguous()) for i in range(K1)]) if K1 > 0 \
-                else torch.empty((0, K2), dtype=torch.float64, device=Z.device)
+            out = torch.empty((K1, K2), dtype=torch.float64, device=Z.device)
         return dev.like_input(out, moment_jacobian1)
 
     def get_moment_jacobian(self, calculate_moments):

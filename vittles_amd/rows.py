@@ -158,6 +158,22 @@ def gemm_tn(A, B, rowscale=None, alpha=1.0, bias=None, out=None):
     return out
 
 
+def gemm_tn_tiled(A, B, tile=8192):
+    """``A^T B`` for operands of ANY width: vt_gemm_tn takes at most 8192 columns per operand, so wider ones are cut
+    into column panels and every (panel of A, panel of B) pair is one vt_gemm_tn call into its slice of the result
+    (no library GEMM on the path)."""
+    Da, Db = A.shape[1], B.shape[1]
+    if Da <= tile and Db <= tile and Da >= 1 and Db >= 1:
+        return gemm_tn(A, B)
+    out = torch.empty((Da, Db), dtype=torch.float64, device=A.device)
+    for i in range(0, Da, tile):
+        Ai = A[:, i:i + tile]
+        for j in range(0, Db, tile):
+            blk = gemm_tn(Ai, B[:, j:j + tile])
+            out[i:i + tile, j:j + tile].copy_(blk)
+    return out
+
+
 def glm_link(obj, theta, w, want_z=False):
     """K0: per-row (z,) r, d for a WeightedGLMObjective."""
     lib = dev.require_gpu()

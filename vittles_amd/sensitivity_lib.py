@@ -81,11 +81,10 @@ def _len(x):
 
 
 def _norm(x):
-    if isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float64:
-        from . import rows
-        return rows.norm(x)
     if isinstance(x, torch.Tensor):
-        return float(torch.linalg.vector_norm(x).item())
+        # fixed-order device reduction (vt_dot3) whatever the tensor's device or dtype was
+        from . import rows
+        return rows.norm(dev.to_device(x.detach().to(torch.float64).reshape(-1)))
     return float(np.linalg.norm(x))
 
 
