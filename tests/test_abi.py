@@ -44,8 +44,8 @@ def test_workspace_queries_need_no_gpu():
     # mid range: at least the NB (NB + 1) chain-order images and the NB inverted diagonal blocks
     assert lib.vt_trsm_pack_bytes(129) >= (9 * 10 + 9) * 256 * 8
     assert lib.vt_trsm_pack_bytes(256) >= (16 * 17 + 16) * 256 * 8
-    # L and L^T images with the even leading dimension 258, and 3 diagonal-block packs
-    assert lib.vt_trsm_pack_bytes(257) == (2 * 257 * 258 + 3 * 2 * 36 * 256) * 8
+    # beyond: L and L^T images with the even leading dimension 258, and the chain packs of two 256-column blocks
+    assert lib.vt_trsm_pack_bytes(257) >= (2 * 257 * 258 + 2 * (16 * 17 + 16) * 256) * 8
     assert lib.vt_trsm_pack_bytes(8193) == 0         # outside what the dense kernels cover
     assert lib.vt_potrf_workspace_bytes(100) >= 0
 

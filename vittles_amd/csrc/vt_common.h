@@ -198,6 +198,8 @@ size_t vt_mid_pack_bytes(int D);
 int vt_mid_pack(const double* L, int ldl, int D, void* pack, hipStream_t st);
 int vt_mid_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
                      int64_t N, double* Out, int64_t ldo, hipStream_t st);
+int vt_mid_trsm_rows_mode(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
+                          int64_t N, double* Out, int64_t ldo, int mode, hipStream_t st);
 bool vt_hess_mid_ok(const double* X, int64_t ldx, int D);
 size_t vt_hess_mid_ws_bytes(int D);
 int vt_hess_mid(int family, const double* X, int64_t ldx, const double* theta, const double* y, const double* w,

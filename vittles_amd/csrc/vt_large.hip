@@ -744,9 +744,23 @@ int vt_large_potrf(double* A, int lda, int D, int* info, void* ws, hipStream_t s
     return vt_launch_status();
 }
 
+// ---- blocked solve, D > 256 -----------------------------------------------------------------------------------
+// Diagonal blocks of kBW = 256 columns, solved by the chain kernels of vt_trsm_mid.h (a full block: forward-only /
+// backward-only halves; the last, partial block: the whole chain of vt_trsm_mid / vt_chol), off-diagonal panels
+// by GEMM-NT updates.  Round 2 used 128-column blocks and the small chain: twice the sweeps over S (each an
+// HBM-bound read + write of N x 128) and twice the update launches; a 256-column block does 4x the MFMA work per
+// byte of its sweep (MFMA-bound at 73 % of peak) and moves a quarter of the flops out of the GEMM.
+// Pack: [Lc | LT | one chain pack per 256-column block].  VT_TRSM_NO_MID=1 keeps the 128-column scheme (dev A/B).
+constexpr int kBW = VT_MID_D_MAX;
+static bool wide_blocks() { return vt_mid_trsm_ok(kBW); }
+static size_t wide_pack_stride() {   // doubles per block pack: the larger of a chain pack and a small pack
+    return (std::max(vt_mid_pack_bytes(kBW), (size_t)kPackStride * sizeof(double)) + 255) / 256 * 256 / sizeof(double);
+}
+
 size_t vt_large_pack_bytes(int D) {
-    const int nblk = (D + kT - 1) / kT;
-    return ((size_t)2 * D * image_ld(D) + (size_t)nblk * kPackStride) * sizeof(double);
+    const int nblk = (D + kT - 1) / kT, nbw = (D + kBW - 1) / kBW;
+    const size_t images = (size_t)2 * D * image_ld(D);
+    return (images + std::max((size_t)nblk * kPackStride, (size_t)nbw * wide_pack_stride())) * sizeof(double);
 }
 
 int vt_large_pack(const double* L, int ldl, int D, void* pack, hipStream_t st) {
@@ -757,6 +771,17 @@ int vt_large_pack(const double* L, int ldl, int D, void* pack, hipStream_t st) {
     int64_t tot = (int64_t)D * Dl;
     hipLaunchKernelGGL(k_copy_lower_and_transpose, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, L, ldl, D,
                        Lc, LT);
+    if (wide_blocks()) {
+        const int nbw = (D + kBW - 1) / kBW;
+        for (int J = 0; J < nbw; ++J) {
+            const int o = J * kBW, Db = std::min(kBW, D - o);
+            double* pk = packs + (size_t)J * wide_pack_stride();
+            int rc = Db > VT_SMALL_D_MAX ? vt_mid_pack(Lc + (int64_t)o * Dl + o, Dl, Db, pk, st)
+                                         : vt_potrf_pack_block(Lc + (int64_t)o * Dl + o, Dl, Db, nullptr, pk, 0, st);
+            if (rc != VT_OK) return rc;
+        }
+        return vt_launch_status();
+    }
     const int nblk = (D + kT - 1) / kT;
     for (int J = 0; J < nblk; ++J) {
         const int o = J * kT, Db = std::min(kT, D - o);
@@ -766,8 +791,50 @@ int vt_large_pack(const double* L, int ldl, int D, void* pack, hipStream_t st) {
     return vt_launch_status();
 }
 
+static int large_trsm_rows_wide(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale,
+                                double alpha, int64_t N, double* Out, int64_t ldo, hipStream_t st) {
+    const int Dl = image_ld(D);
+    const double* Lc = (const double*)pack;
+    const double* LT = Lc + (size_t)D * Dl;
+    const double* packs = LT + (size_t)D * Dl;
+    const int nbw = (D + kBW - 1) / kBW;
+    int rc;
+    // forward:  Y L^T = G with G = alpha * s .* B never materialised (block 0: the chain's row scale; later blocks:
+    // the update's epilogue); the last block runs its forward AND backward chain in one launch
+    for (int J = 0; J < nbw; ++J) {
+        const int o = J * kBW, Db = std::min(kBW, D - o);
+        const double* pk = packs + (size_t)J * wide_pack_stride();
+        const double* src = Out + o;
+        int64_t lds_ = ldo;
+        const double* sc = nullptr;
+        double al = 1.0;
+        if (J == 0) {
+            src = B; lds_ = ldb; sc = rowscale; al = alpha;
+        } else {
+            rc = gemm_nt(Out + o, ldo, N, Db, Out, ldo, Lc + (int64_t)o * Dl, Dl, o, -1.0, 0.0, false, st, B + o, ldb,
+                         rowscale, alpha);
+            if (rc != VT_OK) return rc;
+        }
+        if (J < nbw - 1) rc = vt_mid_trsm_rows_mode(pk, kBW, src, lds_, sc, al, N, Out + o, ldo, 1, st);
+        else if (Db > VT_SMALL_D_MAX) rc = vt_mid_trsm_rows_mode(pk, Db, src, lds_, sc, al, N, Out + o, ldo, 0, st);
+        else rc = vt_trsm_rows_mode(pk, Db, src, lds_, sc, al, N, Out + o, ldo, 0, st);
+        if (rc != VT_OK) return rc;
+    }
+    for (int J = nbw - 2; J >= 0; --J) {   // backward:  Z L = Y
+        const int o = J * kBW, rest = D - o - kBW;
+        rc = gemm_nt(Out + o, ldo, N, kBW, Out + o + kBW, ldo, LT + (int64_t)o * Dl + o + kBW, Dl, rest, -1.0, 1.0,
+                     false, st);
+        if (rc != VT_OK) return rc;
+        rc = vt_mid_trsm_rows_mode(packs + (size_t)J * wide_pack_stride(), kBW, Out + o, ldo, nullptr, 1.0, N, Out + o,
+                                   ldo, 2, st);
+        if (rc != VT_OK) return rc;
+    }
+    return vt_launch_status();
+}
+
 int vt_large_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale,
                        double alpha, int64_t N, double* Out, int64_t ldo, hipStream_t st) {
+    if (wide_blocks()) return large_trsm_rows_wide(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
     const int Dl = image_ld(D);
     const double* Lc = (const double*)pack;
     const double* LT = Lc + (size_t)D * Dl;

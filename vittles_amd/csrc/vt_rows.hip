@@ -496,9 +496,10 @@ int launch_cfg(const RowArgs& a, const RowCfg& c, int grid, bool nt, hipStream_t
     return VT_ERR_UNSUPPORTED;
 }
 
-// Run one row op.  Returns the number of partial slabs written (>0) or an error (<0).
+// Run one row op.  Returns the number of partial slabs written (>0) or an error (<0).  max_slabs > 0: the
+// workspace holds that many slabs -- a launch that would write more is refused BEFORE anything is launched.
 template <int OP, typename XT = double>
-int run_rows(RowArgs a, hipStream_t st) {
+int run_rows(RowArgs a, hipStream_t st, int max_slabs = 0) {
     bool vec2 = (a.D % 2 == 0) && (a.ldx % 2 == 0) && (((uintptr_t)a.X) % (2 * sizeof(XT)) == 0);
     RowCfg c;
     if (!pick_cfg(a.D, vec2, c)) return VT_ERR_UNSUPPORTED;
@@ -506,6 +507,7 @@ int run_rows(RowArgs a, hipStream_t st) {
     // 512-thread teams: one per CU; 256-thread workgroups: up to 4 per CU.
     int cap = c.wg == kWideTeam ? num_cu() : max_grid();
     int grid = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
+    if (max_slabs > 0 && grid > max_slabs) return VT_ERR_SCRATCH_LIMIT;
     // stream X past the caches once it is larger than the Infinity Cache can hold
     bool nt = (double)a.N * a.D * (double)sizeof(XT) > 192.0e6;
     int rc = vec2 ? launch_cfg<OP, 2, XT>(a, c, grid, nt, st) : launch_cfg<OP, 1, XT>(a, c, grid, nt, st);
@@ -705,9 +707,8 @@ extern "C" int vt_glm_hvp_noalloc(const double* X, int64_t ldx, const double* d,
     int P = 0;
     if (N > 0) {
         RowArgs a{X, ldx, N, D, v, nullptr, nullptr, nullptr, d, 1.0, 0, nullptr, nullptr, nullptr, ptr};
-        P = run_rows<OP_HVP>(a, st);
+        P = run_rows<OP_HVP>(a, st, (int)slabs);   // (the slab count is checked before the launch)
         if (P < 0) return P;
-        if ((size_t)P > slabs) return VT_ERR_HIP;   // cannot happen: run_rows caps its grid at `slabs`
     }
     bool has_prior = prior != nullptr || prior_scalar != 0.0;
     return finalize(ptr, D, P, D, 0, 1.0, prior, has_prior ? v : nullptr, prior_scalar, out, st);

@@ -41,11 +41,16 @@ constexpr int kMidCH = 16;                  // images per ring slot
 constexpr int kMidSlot = kMidCH * 256;      // doubles per slot (32 KB)
 constexpr int kMidRingBytes = 3 * kMidSlot * (int)sizeof(double);
 
-template <int NB, int KL, bool LASTPERM>
+template <int NB, int KL, bool LASTPERM, int MODE = 0>
 struct MidTrsmState {
     using S2 = TrsmSched2<NB, KL, LASTPERM>;
     static constexpr int NSET = S2::NSET;
-    static constexpr int M = S2::M;
+    // MODE 0: the whole chain (forward + backward substitution); 1: forward only (Y = L^-1 G stored); 2: backward only
+    // (Z = L^-T Y) -- the two halves of a 256-column diagonal block of the blocked solve for D > 256.  The pack
+    // pointer the kernel gets starts at image BEG; ring slots and chunks count from there.
+    static constexpr int BEG = MODE == 2 ? S2::NBT : 0;
+    static constexpr int END = MODE == 1 ? S2::NBT : S2::M;
+    static constexpr int M = END - BEG;
     static constexpr int NCH = (M + kMidCH - 1) / kMidCH;
     f64x4 V[NB];
     f64x4 acc;
@@ -73,8 +78,8 @@ struct MidTrsmState {
     }
 };
 
-template <int J, int NB, int KL, bool LASTPERM>
-__device__ __forceinline__ void midt_store(MidTrsmState<NB, KL, LASTPERM>& st) {
+template <int J, int NB, int KL, bool LASTPERM, int MODE>
+__device__ __forceinline__ void midt_store(MidTrsmState<NB, KL, LASTPERM, MODE>& st) {
     using S = TrsmSched<NB, KL, LASTPERM>;
     if constexpr (S::permuted(J)) {
         *(f64x2u*)(st.orow + 16 * J + 4 * st.q) = (f64x2u){st.acc[0], st.acc[1]};
@@ -89,9 +94,9 @@ __device__ __forceinline__ void midt_store(MidTrsmState<NB, KL, LASTPERM>& st) {
 }
 
 // before the first read of chunk C of this pass
-template <int C, int NB, int KL, bool LASTPERM>
-__device__ __forceinline__ void midt_boundary(MidTrsmState<NB, KL, LASTPERM>& st) {
-    constexpr int NCH = MidTrsmState<NB, KL, LASTPERM>::NCH;
+template <int C, int NB, int KL, bool LASTPERM, int MODE>
+__device__ __forceinline__ void midt_boundary(MidTrsmState<NB, KL, LASTPERM, MODE>& st) {
+    constexpr int NCH = MidTrsmState<NB, KL, LASTPERM, MODE>::NCH;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     constexpr int cn = C + 2;
     if constexpr (cn < NCH) {
@@ -102,13 +107,14 @@ __device__ __forceinline__ void midt_boundary(MidTrsmState<NB, KL, LASTPERM>& st
 }
 
 // A operand(s) of product IDX -> dst (reads in flight: midt_land waits for them)
-template <int IDX, int NB, int KL, bool LASTPERM>
-__device__ __forceinline__ void midt_fetch(MidTrsmState<NB, KL, LASTPERM>& st,
-                                           double (&dst)[4][MidTrsmState<NB, KL, LASTPERM>::NSET]) {
+template <int IDX, int NB, int KL, bool LASTPERM, int MODE>
+__device__ __forceinline__ void midt_fetch(MidTrsmState<NB, KL, LASTPERM, MODE>& st,
+                                           double (&dst)[4][MidTrsmState<NB, KL, LASTPERM, MODE>::NSET]) {
     using S = TrsmSched2<NB, KL, LASTPERM>;
+    constexpr int REL = IDX - MidTrsmState<NB, KL, LASTPERM, MODE>::BEG;
     constexpr int nks = S::ks(S::src(IDX));
-    constexpr int slot = (IDX / kMidCH) % 3;
-    constexpr int base = (IDX % kMidCH) * 2048;
+    constexpr int slot = (REL / kMidCH) % 3;
+    constexpr int base = (REL % kMidCH) * 2048;
     if constexpr (S::strip_row(IDX)) {
 #pragma unroll
         for (int s = 0; s < nks; ++s)
@@ -121,9 +127,9 @@ __device__ __forceinline__ void midt_fetch(MidTrsmState<NB, KL, LASTPERM>& st,
             asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst[s][0]) : "v"(st.rd[slot]), "n"(base + 512 * s));
     }
 }
-template <int IDX, int NB, int KL, bool LASTPERM>
-__device__ __forceinline__ void midt_land(MidTrsmState<NB, KL, LASTPERM>& st,
-                                          double (&dst)[4][MidTrsmState<NB, KL, LASTPERM>::NSET]) {
+template <int IDX, int NB, int KL, bool LASTPERM, int MODE>
+__device__ __forceinline__ void midt_land(MidTrsmState<NB, KL, LASTPERM, MODE>& st,
+                                          double (&dst)[4][MidTrsmState<NB, KL, LASTPERM, MODE>::NSET]) {
     using S = TrsmSched2<NB, KL, LASTPERM>;
     constexpr int nks = S::ks(S::src(IDX));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -139,15 +145,16 @@ __device__ __forceinline__ void midt_land(MidTrsmState<NB, KL, LASTPERM>& st,
     }
 }
 
-// Products [IDX, M) of the pass; st.cur holds the A operand of product IDX on entry.
-template <int IDX, int NB, int KL, bool LASTPERM>
-__device__ __forceinline__ void midt_chain(MidTrsmState<NB, KL, LASTPERM>& st) {
+// Products [IDX, END) of the pass; st.cur holds the A operand of product IDX on entry.
+template <int IDX, int NB, int KL, bool LASTPERM, int MODE>
+__device__ __forceinline__ void midt_chain(MidTrsmState<NB, KL, LASTPERM, MODE>& st) {
     using S = TrsmSched2<NB, KL, LASTPERM>;
-    constexpr int M = S::M;
-    if constexpr (IDX < M) {
-        constexpr bool more = IDX + 1 < M;
-        constexpr bool edge = more && ((IDX + 1) % kMidCH == 0);   // product IDX + 1 opens a chunk
-        if constexpr (more && !edge) midt_fetch<IDX + 1, NB, KL, LASTPERM>(st, st.nxt);
+    using ST = MidTrsmState<NB, KL, LASTPERM, MODE>;
+    constexpr int END = ST::END, BEG = ST::BEG;
+    if constexpr (IDX < END) {
+        constexpr bool more = IDX + 1 < END;
+        constexpr bool edge = more && ((IDX + 1 - BEG) % kMidCH == 0);   // product IDX + 1 opens a chunk
+        if constexpr (more && !edge) midt_fetch<IDX + 1, NB, KL, LASTPERM, MODE>(st, st.nxt);
         __builtin_amdgcn_sched_barrier(0);
         constexpr int i = S::src(IDX), j = S::row(IDX);
         constexpr int cks = S::ks(i);
@@ -165,29 +172,29 @@ __device__ __forceinline__ void midt_chain(MidTrsmState<NB, KL, LASTPERM>& st) {
         }
         if constexpr (is_last) {
             st.V[j] = st.acc;
-            if (is_bwd && st.store) midt_store<j, NB, KL, LASTPERM>(st);
+            if ((is_bwd || MODE == 1) && st.store) midt_store<j, NB, KL, LASTPERM, MODE>(st);
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (edge) {
             // (the MFMAs just issued cover the barrier; the chunk's first operands are read behind it)
-            midt_boundary<(IDX + 1) / kMidCH, NB, KL, LASTPERM>(st);
-            midt_fetch<IDX + 1, NB, KL, LASTPERM>(st, st.nxt);
+            midt_boundary<(IDX + 1 - BEG) / kMidCH, NB, KL, LASTPERM, MODE>(st);
+            midt_fetch<IDX + 1, NB, KL, LASTPERM, MODE>(st, st.nxt);
         }
         if constexpr (more) {
-            midt_land<IDX + 1, NB, KL, LASTPERM>(st, st.nxt);
+            midt_land<IDX + 1, NB, KL, LASTPERM, MODE>(st, st.nxt);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int r = 0; r < S::NSET; ++r) st.cur[s][r] = st.nxt[s][r];
         }
-        midt_chain<IDX + 1, NB, KL, LASTPERM>(st);
+        midt_chain<IDX + 1, NB, KL, LASTPERM, MODE>(st);
     }
 }
 
-template <int NB, int KL, bool LASTPERM>
+template <int NB, int KL, bool LASTPERM, int MODE = 0>
 __global__ __launch_bounds__(512) void k_trsm_rows_mid(MidTrsmArgs a) {
     using S = TrsmSched<NB, KL, LASTPERM>;
-    using ST = MidTrsmState<NB, KL, LASTPERM>;
+    using ST = MidTrsmState<NB, KL, LASTPERM, MODE>;
     constexpr int NCH = ST::NCH;
     static_assert(NCH >= 3, "the ring holds three chunks");
     extern __shared__ double ring[];
@@ -277,30 +284,31 @@ __global__ __launch_bounds__(512) void k_trsm_rows_mid(MidTrsmArgs a) {
         const int64_t row = grp * 16 + n;
         st.store = row < a.N;
         st.orow = a.Out + (st.store ? row : 0) * a.ldo;
-        midt_boundary<0, NB, KL, LASTPERM>(st);
+        midt_boundary<0, NB, KL, LASTPERM, MODE>(st);
         if constexpr (PREFETCH) {   // (behind the boundary: its vmcnt(0) would wait for these loads)
             const int64_t gnext = group_of(it + 1);
             load_group(st.has_next && gnext < ngroups ? gnext : (grp < ngroups ? grp : 0), Gn, coefn);
         }
-        midt_fetch<0, NB, KL, LASTPERM>(st, st.cur);
-        midt_land<0, NB, KL, LASTPERM>(st, st.cur);
-        midt_chain<0, NB, KL, LASTPERM>(st);
+        midt_fetch<ST::BEG, NB, KL, LASTPERM, MODE>(st, st.cur);
+        midt_land<ST::BEG, NB, KL, LASTPERM, MODE>(st, st.cur);
+        midt_chain<ST::BEG, NB, KL, LASTPERM, MODE>(st);
         rot = (rot + NCH) % 3;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-template <int NB, int KL, bool LASTPERM>
+template <int NB, int KL, bool LASTPERM, int MODE = 0>
 int midt_launch(const MidTrsmArgs& a0, hipStream_t st) {
     MidTrsmArgs a = a0;
+    a.pack += (size_t)MidTrsmState<NB, KL, LASTPERM, MODE>::BEG * 256;   // the stream starts at the mode's first image
     static VtLdsAttr attr;   // per kernel instantiation, per device
-    if (vt_allow_big_lds((const void*)k_trsm_rows_mid<NB, KL, LASTPERM>, attr, kMidRingBytes) != VT_OK) return VT_ERR_HIP;
+    if (vt_allow_big_lds((const void*)k_trsm_rows_mid<NB, KL, LASTPERM, MODE>, attr, kMidRingBytes) != VT_OK) return VT_ERR_HIP;
     const int64_t ngroups = (a.N + 15) / 16;
     int64_t g = (ngroups + 7) / 8;
     if (g > vt_num_cu()) g = vt_num_cu();
     if (g < 1) g = 1;
     a.npass = (int)((ngroups + g * 8 - 1) / (g * 8));
-    hipLaunchKernelGGL((k_trsm_rows_mid<NB, KL, LASTPERM>), dim3((int)g), dim3(512), kMidRingBytes, st, a);
+    hipLaunchKernelGGL((k_trsm_rows_mid<NB, KL, LASTPERM, MODE>), dim3((int)g), dim3(512), kMidRingBytes, st, a);
     return VT_OK;
 }
 

@@ -12,6 +12,9 @@ int vt_mid_trsm_b(const void* pack, int D, const double* B, int64_t ldb, const d
 int vt_mid_trsm_c(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
                   int64_t N, double* Out, int64_t ldo, hipStream_t st);
 
+int vt_mid_trsm_d(const void* pack, const double* B, int64_t ldb, const double* rowscale, double alpha, int64_t N,
+                  double* Out, int64_t ldo, int mode, hipStream_t st);
+
 namespace {
 
 // Linv_JJ of every 16 x 16 diagonal block (padding rows past D: identity).  One wave per block, lane c = column c:
@@ -88,6 +91,15 @@ inline int mid_images(int D) {
 }
 
 }  // namespace
+
+// mode 0: full solve (any 129 <= D <= 256); 1 / 2: forward-only / backward-only (D = 256 only)
+int vt_mid_trsm_rows_mode(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
+                          int64_t N, double* Out, int64_t ldo, int mode, hipStream_t st) {
+    if (mode == 0) return vt_mid_trsm_rows(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
+    if (D != VT_MID_D_MAX) return VT_ERR_UNSUPPORTED;
+    if (N == 0) return VT_OK;
+    return vt_mid_trsm_d(pack, B, ldb, rowscale, alpha, N, Out, ldo, mode, st);
+}
 
 bool vt_mid_trsm_ok(int D) {
     static const bool off = getenv("VT_TRSM_NO_MID") != nullptr;   // dev A/B switch, read once
