@@ -538,6 +538,41 @@ def config3_leg(torch, dist, va, DeviceCholesky, world, rank, device, group, col
                           "checksum_all_rows_rel_err": err_sum,
                           "H_first_rows_rel_err_vs_numpy": rel(H_sub, H_ref), "H_first_rows": int(n_sub),
                           "H_identical_on_all_ranks": bool(same), "tolerance": 1e-9}}
+    if world == 1 and rank == 0 and dim <= 4096:
+        # the optional fp32 STORAGE mode at this D (row n1): X and S float (half the footprint), fp64 products on
+        # float panels, slab-wise fp64 solve; reported beside the fp64 figures, never as `value`
+        S64_rows = S[di].clone()
+        del S
+        X32 = X.to(torch.float32)
+        obj32 = va.WeightedGLMObjective(X32, y, family="logistic", prior=1.0, dtype=torch.float32)
+        S32 = torch.empty((n_local, dim), dtype=torch.float32, device=device)
+        ev32 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        for rep in range(2):
+            obj32.invalidate_cache()
+            ev32[0].record()
+            o32 = obj32.fused(theta, w)
+            ev32[1].record()
+            c32 = DeviceCholesky.factor(o32["H"], check=False, pack=True)
+            ev32[2].record()
+            c32.solve_rows(obj32.X, rowscale=o32["r"], alpha=-1.0, out=S32)
+            ev32[3].record()
+            c32.raise_if_failed()
+        torch.cuda.synchronize()
+        t32 = [ev32[i].elapsed_time(ev32[i + 1]) for i in range(3)]
+        res["fp32_mode"] = {
+            "note": "optional fp32 STORAGE mode at D=%d: X and S float (%.1f GB each instead of %.1f), link / r / d / H / "
+                    "g / Cholesky double, SYRK on float panels with fp64 products, solve in fp64 row slabs; reduced "
+                    "precision, never `value`" % (dim, 4e-9 * n_local * dim, 8e-9 * n_local * dim),
+            "stages_ms": {"fused_link_grad_hessian": t32[0], "cholesky_pack": t32[1], "sens_trsm": t32[2]},
+            "sensitivities_per_s": n_local / (sum(t32) * 1e-3),
+            "syrk_TFLOPs": float(n_local) * dim * (dim + 1) / (t32[0] * 1e-3) / 1e12,
+            "trsm_TFLOPs": 2.0 * dim * dim * n_local / (t32[2] * 1e-3) / 1e12,
+            "tolerance": 1e-4,
+            "H_max_rel_err_vs_fp64": float(((o32["H"] - out["H"]).abs().max() / out["H"].abs().max()).item()),
+            "S_sampled_rows_rel_err_vs_fp64": float(((S32[di].double() - S64_rows).abs().max()
+                                                     / S64_rows.abs().max()).item())}
+        del X32, obj32, S32, o32, c32
+        S = None
     del X, S, obj
     torch.cuda.empty_cache()
     return res

@@ -270,6 +270,16 @@ int    vt_trsm_pack_f32(const void* pack_dev, int D, void* pack32_dev, void* str
 int    vt_trsm_rows_f32(const void* pack32_dev, int D, const float* B_dev, int64_t ldb,
                         const double* rowscale_dev, double alpha, int64_t N, float* Out_dev, int64_t ldo,
                         void* stream);
+/* D > VT_SMALL_D_MAX in the fp32 mode (configs[2]'s D = 1000 with float X and S: half the 160 GB footprint):
+ * vt_glm_hessian_f32 takes D <= 4096 (float row kernel for link + gradient, tiled SYRK with float panels, every
+ * product and sum in fp64); the solve below takes the ORDINARY fp64 pack of vt_potrf_pack / vt_trsm_pack and a
+ * scratch of vt_trsm_rows_f32_large_workspace_bytes(N, D) bytes (a slab of rows is widened to double, solved by
+ * the fp64 kernels and narrowed into the float result; a smaller scratch means more, smaller slabs).
+ * Replaces: the same lines as vt_trsm_rows (vittles/sensitivity_lib.py:226, vittles/solver_lib.py:28-29). */
+size_t vt_trsm_rows_f32_large_workspace_bytes(int64_t N, int D);
+int    vt_trsm_rows_f32_large(const void* pack_dev, int D, const float* B_dev, int64_t ldb,
+                              const double* rowscale_dev, double alpha, int64_t N, float* Out_dev, int64_t ldo,
+                              void* ws_dev, size_t ws_bytes, void* stream);
 /* the row operators (workspace: vt_rows_workspace_bytes(D), as for the fp64 ones) */
 int    vt_glm_link_f32(int family, const float* X_dev, int64_t ldx, const double* theta_dev,
                        const double* y_dev, const double* w_dev, const double* offset_dev, double scale,

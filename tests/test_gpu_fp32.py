@@ -240,7 +240,7 @@ def test_fp32_limits_raise_clearly():
     torch = _torch()
     import vittles_amd as va
     from vittles_amd._lib import VittlesHipError
-    X, y, w, theta, _ = _problem(300, 200, "logistic", seed=2)
+    X, y, w, theta, _ = _problem(30, 4100, "logistic", seed=2)      # past the float row kernels' D <= 4096
     obj = va.WeightedGLMObjective(X, y, prior=1.0, dtype=torch.float32)
     with pytest.raises(VittlesHipError) as e:
         obj.fused(theta, w)
@@ -293,3 +293,61 @@ def test_fp32_predict_batch_matches_loop(relerr):
         one = lin32.predict_opt_par_from_hyper_par(W[:, k])
         assert relerr(got[:, k].cpu().numpy(), one.cpu().numpy()) < EXACT
     assert relerr(got.cpu().numpy(), lin64.predict_opt_par_from_hyper_par_batch(W).cpu().numpy()) < MODE
+
+
+# ---- D > 128 in the fp32 storage mode: float X and S, tiled SYRK on float panels with fp64
+# products, slab-wise fp64 solve -- configs[2]'s D = 1000 at half the footprint ----------------------------------
+@pytest.mark.parametrize("N,D,family", [(3000, 129, "logistic"), (5000, 160, "poisson"), (4100, 257, "gaussian"),
+                                         (6001, 1000, "logistic"), (2500, 1001, "logistic"), (4000, 384, "logistic")])
+def test_fp32_large_d_hessian_and_sensitivity(N, D, family, relerr):
+    torch = _torch()
+    from oracle import glm
+    import vittles_amd as va
+    X, y, w, _, _ = _problem(N, D, family, seed=N + D)
+    prior = 1.0
+    theta = glm.newton_optimum(family, X, y, w, prior=prior)
+    obj = va.WeightedGLMObjective(X, y, family=family, prior=prior, dtype=torch.float32)
+    assert obj.X.dtype == torch.float32 and obj.X.stride(0) % 4 == 0
+    out = obj.fused(theta, w)
+    H = out["H"].cpu().numpy()
+    assert out["H"].dtype == torch.float64 and np.array_equal(H, H.T)
+    # the products and sums are fp64: against the oracle on the ROUNDED X the Hessian is fp64-exact
+    X32 = X.astype(np.float32).astype(np.float64)
+    assert relerr(H, glm.hessian(family, X32, y, theta, w, prior)) < 1e-10
+    assert relerr(out["g"].cpu().numpy() + 1.0, glm.grad(family, X32, y, theta, w, prior) + 1.0) < 1e-10
+    # and within the mode's tolerance of the fp64 oracle on the caller's X
+    H_ref, _, S_ref = glm.sensitivity(family, X, y, theta, w, prior=prior)
+    assert relerr(H, H_ref) < MODE
+    sens = va.HyperparameterSensitivityLinearApproximation(obj, theta, w)
+    S = sens.get_dopt_dhyper()
+    assert S.shape == (D, N) and sens._sens_rows.dtype == torch.float32
+    assert relerr(S, S_ref) < MODE
+    w1 = w * (1.0 + 0.01 * np.cos(np.arange(N)))
+    assert relerr(sens.predict_opt_par_from_hyper_par(w1), theta + S_ref @ (w1 - w)) < MODE
+
+
+def test_fp32_large_d_solve_in_slabs(relerr):
+    """vt_trsm_rows_f32_large with a scratch smaller than the matrix: several slabs, ragged last one."""
+    torch = _torch()
+    import scipy.linalg
+    from vittles_amd import _lib, device as dev
+    from vittles_amd.linalg import DeviceCholesky
+    rng = np.random.default_rng(5)
+    D, N = 300, 20000
+    A = rng.standard_normal((2 * D, D))
+    Hm = A.T @ A / D + np.eye(D)
+    chol = DeviceCholesky.factor(torch.tensor(Hm, device="cuda"), pack=True)
+    B = rng.standard_normal((N, D)).astype(np.float32)
+    s = 0.5 + rng.random(N)
+    Bd, sd = torch.tensor(B, device="cuda"), torch.tensor(s, device="cuda")
+    out = torch.empty((N, D), dtype=torch.float32, device="cuda")
+    ws = torch.empty(6000 * D, dtype=torch.float64, device="cuda")        # 6000 rows per slab: 4 slabs
+    lib = _lib.load()
+    _lib.check(lib.vt_trsm_rows_f32_large(chol.pack().data_ptr(), D, Bd.data_ptr(), D, sd.data_ptr(), -2.0, N,
+                                          out.data_ptr(), D, ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "slabs")
+    ref = -2.0 * s[:, None] * scipy.linalg.cho_solve(scipy.linalg.cho_factor(Hm), B.astype(np.float64).T).T
+    assert relerr(out.cpu().numpy().astype(np.float64), ref) < 1e-6
+    assert torch.equal(chol.solve_rows(Bd, rowscale=sd, alpha=-2.0), out)   # the one-slab route gives the same floats
+    tiny = torch.empty(10 * D, dtype=torch.float64, device="cuda")
+    assert lib.vt_trsm_rows_f32_large(chol.pack().data_ptr(), D, Bd.data_ptr(), D, 0, 1.0, N, out.data_ptr(), D,
+                                      tiny.data_ptr(), tiny.numel() * 8, dev.stream_ptr()) == -3   # VT_ERR_WORKSPACE

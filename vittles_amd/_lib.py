@@ -90,6 +90,9 @@ SIGNATURES = {
     "vt_trsm_pack_f32_bytes": (c_size_t, [c_int]),
     "vt_trsm_pack_f32": (c_int, [c_ptr, c_int, c_ptr, c_ptr]),
     "vt_trsm_rows_f32": (c_int, [c_ptr, c_int, c_ptr, c_i64, c_ptr, c_dbl, c_i64, c_ptr, c_i64, c_ptr]),
+    "vt_trsm_rows_f32_large_workspace_bytes": (c_size_t, [c_i64, c_int]),
+    "vt_trsm_rows_f32_large": (c_int, [c_ptr, c_int, c_ptr, c_i64, c_ptr, c_dbl, c_i64, c_ptr, c_i64, c_ptr, c_size_t,
+                                       c_ptr]),
     "vt_glm_link_f32": (c_int, [c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_i64, c_int,
                                 c_ptr, c_ptr, c_ptr, c_ptr, c_size_t, c_ptr]),
     "vt_glm_grad_f32": (c_int, [c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_ptr, c_i64, c_int,

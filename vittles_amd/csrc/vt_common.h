@@ -206,5 +206,7 @@ int vt_hess_mid(int family, const double* X, int64_t ldx, const double* theta, c
                 const double* offset, double scale, int64_t N, int D, double* r, double* d, double* part,
                 int* nslabs, hipStream_t st);
 size_t vt_large_syrk_ws_bytes(int D);
+int vt_large_syrk_f32(const float* X, int64_t ldx, const double* d, int64_t N, int D, const double* prior, double* H,
+                      int ldh, void* ws, hipStream_t st);
 int vt_large_syrk(const double* X, int64_t ldx, const double* d, int64_t N, int D, const double* prior, double* H,
                   int ldh, void* ws, hipStream_t st);

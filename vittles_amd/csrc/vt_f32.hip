@@ -263,9 +263,21 @@ void launch_trsm32(const Trsm32Args& a, hipStream_t st) {
 
 }  // namespace
 
+// D > 128 in the fp32 storage mode: link + gradient by the float row kernel (one pass over the float X), then the
+// tiled SYRK with float panels (vt_large.hip: k_syrk_lds<..., AT = float>) -- half the HBM bytes of the fp64 path,
+// every product and sum in fp64.  The row kernels bound it at D <= 4096.
+extern "C" size_t vt_rows_workspace_bytes(int D);
+extern "C" int vt_glm_grad_f32(int family, const float* X, int64_t ldx, const double* theta, const double* y,
+                               const double* w, const double* offset, double scale, const double* prior, int64_t N,
+                               int D, double* g_out, double* r_out, double* d_out, void* ws, size_t ws_bytes,
+                               void* stream);
+constexpr int kF32LargeDMax = 4096;
+static size_t large32_ws_rows(int D) { return (vt_rows_workspace_bytes(D) + 255) / 256 * 256; }
+
 extern "C" size_t vt_glm_hessian_f32_workspace_bytes(int64_t N, int D) {
-    (void)N;
-    if (D < 1 || D > VT_SMALL_D_MAX) return 0;
+    if (D < 1 || D > kF32LargeDMax || N < 0) return 0;
+    if (D > VT_SMALL_D_MAX)
+        return large32_ws_rows(D) + ((size_t)(N + D + 64) * sizeof(double) + 255) / 256 * 256 + vt_large_syrk_ws_bytes(D);
     return ((size_t)vt_num_cu() * hs_slab_len((D + 15) / 16) + 1024) * sizeof(double);
 }
 
@@ -276,9 +288,20 @@ extern "C" int vt_glm_hessian_f32(int family, const float* X, int64_t ldx, const
     if (!theta || !H || N < 0 || D < 1 || ldx < D || ldh < D) return VT_ERR_BAD_ARG;
     if (N > 0 && (!X || !y || !w)) return VT_ERR_BAD_ARG;
     if (family < 0 || family > 2) return VT_ERR_BAD_ARG;
-    if (D > VT_SMALL_D_MAX) return VT_ERR_UNSUPPORTED;   // the fp32 mode covers the MFMA-resident shapes only
+    if (D > kF32LargeDMax) return VT_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < vt_glm_hessian_f32_workspace_bytes(N, D)) return VT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (D > VT_SMALL_D_MAX) {
+        char* base = (char*)ws;
+        double* dtmp = (double*)(base + large32_ws_rows(D));
+        double* gtmp = dtmp + N;
+        void* syrk_ws = (void*)(base + large32_ws_rows(D) + ((size_t)(N + D + 64) * sizeof(double) + 255) / 256 * 256);
+        double* dd = d ? d : dtmp;
+        int rc = vt_glm_grad_f32(family, X, ldx, theta, y, w, offset, scale, prior, N, D, g ? g : gtmp, r, dd, ws,
+                                 large32_ws_rows(D), stream);
+        if (rc != VT_OK) return rc;
+        return vt_large_syrk_f32(X, ldx, dd, N, D, prior, H, ldh, syrk_ws, st);
+    }
     const int NB = (D + 15) / 16;
     const int L = hs_slab_len(NB);
     double* part = (double*)ws;
@@ -360,6 +383,62 @@ extern "C" int vt_trsm_rows_f32(const void* pack32, int D, const float* B, int64
         case 7: launch_trsm32<7>(a, st); break;
         case 8: launch_trsm32<8>(a, st); break;
         default: return VT_ERR_UNSUPPORTED;
+    }
+    return vt_launch_status();
+}
+
+// ---- fp32 storage mode, D > 128: the sensitivity solve in row slabs -------------------------------------------
+// Out (float) [n, :] = alpha * s_n * (L L^T)^{-1} B (float) [n, :]: a slab of rows is widened into a double scratch,
+// solved in place by the fp64 chain / blocked kernels (vt_trsm_rows with the ordinary fp64 pack) and narrowed into
+// the float result.  Storage (X and S: 4 N D bytes each) is what the mode halves; the solve itself is MFMA-bound at
+// these D, and the two conversions add 24 bytes of traffic per element of a slab.
+namespace {
+__global__ void k_widen_rows(const float* B, int64_t ldb, int64_t n, int D, double* W, int64_t ldw) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tot = n * ldw;
+    if (idx >= tot) return;
+    const int64_t r = idx / ldw;
+    const int c = (int)(idx - r * ldw);
+    W[idx] = c < D ? (double)B[r * ldb + c] : 0.0;
+}
+__global__ void k_narrow_rows(const double* W, int64_t ldw, int64_t n, int D, float* Out, int64_t ldo) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * D) return;
+    const int64_t r = idx / D;
+    const int c = (int)(idx - r * D);
+    Out[r * ldo + c] = (float)W[r * ldw + c];
+}
+constexpr int64_t kSlabRows = 131072;   // 512 rows per CU: the persistent solve kernels stay filled
+}  // namespace
+
+extern "C" int vt_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
+                            int64_t N, double* Out, int64_t ldo, void* stream);
+
+extern "C" size_t vt_trsm_rows_f32_large_workspace_bytes(int64_t N, int D) {
+    if (N < 0 || D <= VT_SMALL_D_MAX || D > VT_DENSE_D_MAX) return 0;
+    return (size_t)std::min<int64_t>(std::max<int64_t>(N, 1), kSlabRows) * (size_t)(D + (D & 1)) * sizeof(double);
+}
+
+extern "C" int vt_trsm_rows_f32_large(const void* pack, int D, const float* B, int64_t ldb, const double* rowscale,
+                                      double alpha, int64_t N, float* Out, int64_t ldo, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    if (!pack || D < 1 || ldb < D || ldo < D || N < 0) return VT_ERR_BAD_ARG;
+    if (D <= VT_SMALL_D_MAX || D > VT_DENSE_D_MAX) return VT_ERR_UNSUPPORTED;
+    if (N == 0) return VT_OK;
+    if (!B || !Out) return VT_ERR_BAD_ARG;
+    const int64_t ldw = D + (D & 1);
+    const int64_t slab = ws ? (int64_t)(ws_bytes / ((size_t)ldw * sizeof(double))) : 0;
+    if (slab < std::min<int64_t>(N, 4096)) return VT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    double* W = (double*)ws;
+    for (int64_t r0 = 0; r0 < N; r0 += slab) {
+        const int64_t n = std::min(slab, N - r0);
+        hipLaunchKernelGGL(k_widen_rows, dim3((unsigned)((n * ldw + 255) / 256)), dim3(256), 0, st, B + r0 * ldb, ldb, n, D,
+                           W, ldw);
+        int rc = vt_trsm_rows(pack, D, W, ldw, rowscale ? rowscale + r0 : nullptr, alpha, n, W, ldw, stream);
+        if (rc != VT_OK) return rc;
+        hipLaunchKernelGGL(k_narrow_rows, dim3((unsigned)((n * D + 255) / 256)), dim3(256), 0, st, (const double*)W, ldw, n,
+                           D, Out + r0 * ldo, ldo);
     }
     return vt_launch_status();
 }

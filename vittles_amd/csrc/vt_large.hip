@@ -357,7 +357,7 @@ struct SyrkPlan {
 };
 
 struct SyrkArgs {
-    const double* X;
+    const void* X;   // double, or float in the fp32 storage mode (k_syrk_*<..., AT = float>)
     int64_t ldx;
     const double* d;
     int64_t N;
@@ -447,7 +447,7 @@ inline int syrk_tile_cost(bool diag, int icols, int jcols) {
     return std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3])) + c0;
 }
 
-template <bool GEN, typename BT = double>
+template <bool GEN, typename BT = double, typename AT = double>
 __global__ __launch_bounds__(256) void k_syrk_tile(SyrkArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, c = lane & 15;
@@ -483,12 +483,12 @@ __global__ __launch_bounds__(256) void k_syrk_tile(SyrkArgs a) {
             int64_t n = s * 4 + q;
             bool ok = s < s1 && n < a.N;
             int64_t nc = n < a.N ? n : a.N - 1;
-            const double* xr = a.X + nc * a.ldx;
+            const AT* xr = (const AT*)a.X + nc * a.ldx;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                b.xa[i] = xr[ca[i]];
+                b.xa[i] = (double)xr[ca[i]];
                 if constexpr (GEN) b.xb[i] = (double)((const BT*)a.B + nc * a.ldb)[cb[i]];
-                else b.xb[i] = xr[cb[i]];
+                else b.xb[i] = (double)xr[cb[i]];
             }
             double dv = a.d ? a.d[nc] : 1.0;
             b.dn = ok ? dv : 0.0;
@@ -534,9 +534,13 @@ __global__ __launch_bounds__(256) void k_syrk_tile(SyrkArgs a) {
 // share a CU (4 waves per SIMD) and cover each other's barrier and DMA waits.
 // BT = float (GEN only): the second operand is stored in float (the fp32 storage mode's S); its panel rows are
 // 512 bytes of the same LDS slots and the B operand is converted as it is read.
-template <bool GEN, int STAGES, typename BT = double>
+// AT = float: the first operand (the SYRK's only one) is stored in float -- the fp32 storage mode's X for D > 128:
+// half the DMA bytes, products and sums still fp64 (the operands are widened as they are read, so the result is the
+// fp64 Hessian of the rounded data).
+template <bool GEN, int STAGES, typename BT = double, typename AT = double>
 __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
-    static_assert(GEN || std::is_same<BT, double>::value, "the SYRK has one (double) operand");
+    static_assert(GEN || std::is_same<BT, double>::value, "the SYRK has one operand (its type is AT)");
+    using JT = typename std::conditional<GEN, BT, AT>::type;   // storage type of the column-side panel
     extern __shared__ double lds[];            // [STAGES][I: 16 x 144 | J: 16 x 144]
     constexpr int RSTR = kT + 16, PANEL = kKC * RSTR;
     const int lane = threadIdx.x & 63;
@@ -563,8 +567,8 @@ __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
             const int64_t row = r0 + (int64_t)t * kKC + n;
             const bool ok = t < nk && row < r1;
             const void* base = (GEN && isj) ? (const void*)((const BT*)a.B + (ok ? row : 0) * a.ldb + tj * kT)
-                                            : (const void*)(a.X + (ok ? row : 0) * a.ldx + (isj ? tj : ti) * kT);
-            const unsigned bytes = ok ? ((GEN && isj) ? (unsigned)sizeof(BT) : 8u) * (isj ? jcols : icols) : 0u;
+                                            : (const void*)((const AT*)a.X + (ok ? row : 0) * a.ldx + (isj ? tj : ti) * kT);
+            const unsigned bytes = ok ? ((GEN && isj) ? (unsigned)sizeof(BT) : (unsigned)sizeof(AT)) * (isj ? jcols : icols) : 0u;
             double* dst = lds + buf * (2 * PANEL) + (isj ? PANEL : 0) + n * RSTR;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(lg_rsrc(base, bytes), (vt_ldsptr)dst, 16, 16u * lane, 0, 0, 0);
         }
@@ -604,16 +608,17 @@ __global__ __launch_bounds__(512) void k_syrk_lds(SyrkArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         if (mask != 0u) {
-            constexpr int BR = (int)(sizeof(double) / sizeof(BT));   // B elements per double of LDS
-            const double* pa = lds + buf * (2 * PANEL) + q * RSTR + 64 * wm + c;
-            const BT* pb = (const BT*)(lds + buf * (2 * PANEL) + PANEL + q * RSTR) + 32 * wn + c;
+            constexpr int BR = (int)(sizeof(double) / sizeof(JT));   // panel elements per double of LDS
+            constexpr int AR = (int)(sizeof(double) / sizeof(AT));
+            const AT* pa = (const AT*)(lds + buf * (2 * PANEL) + q * RSTR) + 64 * wm + c;
+            const JT* pb = (const JT*)(lds + buf * (2 * PANEL) + PANEL + q * RSTR) + 32 * wn + c;
             {   // only the blocks of the mask (scalar branches; a second, unmasked copy of the loop for full tiles cost
                 // 74 more VGPRs and the second workgroup per CU)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     double af[4], bf[2];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = pa[4 * s * RSTR + 16 * i];
+                    for (int i = 0; i < 4; ++i) af[i] = (double)pa[4 * s * RSTR * AR + 16 * i];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) bf[j] = dcur[s] * (double)pb[4 * s * RSTR * BR + 16 * j];
 #pragma unroll
@@ -957,27 +962,41 @@ size_t vt_large_syrk_ws_bytes(int D) {
     return (size_t)std::max(kSyrkMaxRounds * 2 * num_cu(), 8 * ntl) * kT * kT * sizeof(double);
 }
 
-int vt_large_syrk(const double* X, int64_t ldx, const double* d, int64_t N, int D, const double* prior, double* H,
-                  int ldh, void* ws, hipStream_t st) {
+template <typename AT>
+static int large_syrk_impl(const AT* X, int64_t ldx, const double* d, int64_t N, int D, const double* prior, double* H,
+                           int ldh, void* ws, hipStream_t st) {
     const int nt = (D + kT - 1) / kT, ntl = nt * (nt + 1) / 2;
     SyrkPlan plan = syrk_plan(D, N);
     SyrkArgs a{X, ldx, d, N, D, nt, plan, (double*)ws, nullptr, 0, 0, 0};
+    constexpr int kPer16 = 16 / (int)sizeof(AT);   // elements per 16-byte DMA lane
     if (N == 0) {
         for (int c = 0; c < 4; ++c) plan.s[c] = 0;   // no rows: the reduce below sums zero slabs and adds the prior
-    } else if (ldx % 2 == 0 && (uintptr_t)X % 16 == 0 && !large_no_lds()) {
+    } else if (ldx % kPer16 == 0 && (uintptr_t)X % 16 == 0 && !large_no_lds()) {
         const size_t shmem = (size_t)large_stages() * 2 * kKC * (kT + 16) * sizeof(double);   // 108 / 72 KB
         static VtLdsAttr attr[2];
-        if (vt_allow_big_lds((const void*)k_syrk_lds<false, 3>, attr[0], (int)shmem) != VT_OK ||
-            vt_allow_big_lds((const void*)k_syrk_lds<false, 2>, attr[1], (int)shmem) != VT_OK)
+        if (vt_allow_big_lds((const void*)k_syrk_lds<false, 3, double, AT>, attr[0], (int)shmem) != VT_OK ||
+            vt_allow_big_lds((const void*)k_syrk_lds<false, 2, double, AT>, attr[1], (int)shmem) != VT_OK)
             return VT_ERR_HIP;
-        if (large_stages() == 2) hipLaunchKernelGGL((k_syrk_lds<false, 2>), dim3(8 * plan.per_xcd), dim3(512), shmem, st, a);
-        else hipLaunchKernelGGL((k_syrk_lds<false, 3>), dim3(8 * plan.per_xcd), dim3(512), shmem, st, a);
+        if (large_stages() == 2)
+            hipLaunchKernelGGL((k_syrk_lds<false, 2, double, AT>), dim3(8 * plan.per_xcd), dim3(512), shmem, st, a);
+        else
+            hipLaunchKernelGGL((k_syrk_lds<false, 3, double, AT>), dim3(8 * plan.per_xcd), dim3(512), shmem, st, a);
     } else {
-        hipLaunchKernelGGL(k_syrk_tile<false>, dim3(8 * plan.per_xcd), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_syrk_tile<false, double, AT>), dim3(8 * plan.per_xcd), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(k_syrk_reduce, dim3(kT * kT / 256, ntl), dim3(256), 0, st, (const double*)ws, nt, plan, D, prior,
                        H, ldh);
     return vt_launch_status();
+}
+
+int vt_large_syrk(const double* X, int64_t ldx, const double* d, int64_t N, int D, const double* prior, double* H,
+                  int ldh, void* ws, hipStream_t st) {
+    return large_syrk_impl<double>(X, ldx, d, N, D, prior, H, ldh, ws, st);
+}
+// fp32 storage mode, D > 128: X in float (half the bytes), every product and sum in fp64
+int vt_large_syrk_f32(const float* X, int64_t ldx, const double* d, int64_t N, int D, const double* prior, double* H,
+                      int ldh, void* ws, hipStream_t st) {
+    return large_syrk_impl<float>(X, ldx, d, N, D, prior, H, ldh, ws, st);
 }
 
 // ------------------------------------------------------------------ two-operand product -------

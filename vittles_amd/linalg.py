@@ -14,6 +14,7 @@ class DeviceCholesky:
         self.D = L.shape[0]
         self._pack = pack           # MFMA TRSM operand images (lazy)
         self._pack32 = None         # the same images in float for the fp32 storage mode (lazy)
+        self._slab_ws = None        # double scratch of the fp32 mode's slab-wise solve at D > 128 (lazy)
         self._info = info           # device int32: LAPACK-style potrf info (None = known good)
 
     def raise_if_failed(self):
@@ -159,6 +160,19 @@ class DeviceCholesky:
         if B.dtype == torch.float32:
             if out.dtype != torch.float32:
                 raise ValueError("out must be float32 like B")
+            if D > _lib.SMALL_D_MAX:
+                # fp32 storage at D > 128: slabs of rows widened into a double scratch, solved by the fp64 kernels
+                # with the ordinary pack and narrowed into the float result (csrc/vt_f32.hip)
+                nbytes = lib.vt_trsm_rows_f32_large_workspace_bytes(N, D)
+                if nbytes == 0:
+                    raise _lib.VittlesHipError("the fp32 mode's solve supports D <= 8192 (got %d)" % D)
+                ws = self._slab_ws
+                if ws is None or ws.numel() * 8 < nbytes or ws.device != B.device:
+                    ws = self._slab_ws = torch.empty(nbytes // 8, dtype=torch.float64, device=B.device)
+                _lib.check(lib.vt_trsm_rows_f32_large(self.pack().data_ptr(), D, B.data_ptr(), ldb, dev.ptr(rowscale),
+                                                      float(alpha), N, out.data_ptr(), ldo, ws.data_ptr(), ws.numel() * 8,
+                                                      dev.stream_ptr()), "vt_trsm_rows_f32_large")
+                return out
             _lib.check(lib.vt_trsm_rows_f32(self.pack32().data_ptr(), D, B.data_ptr(), ldb, dev.ptr(rowscale),
                                             float(alpha), N, out.data_ptr(), ldo, dev.stream_ptr()),
                        "vt_trsm_rows_f32")

@@ -60,13 +60,16 @@ def _aligned_rows(X):
     N, D = X.shape
     # narrow designs (D <= 80) run the row-link kernel, which takes any 8-byte aligned rows, and are HBM-bound:
     # padded rows would only add traffic (D = 15, N = 10^6: solve 0.040 ms dense, 0.063 ms padded)
-    if not RELAYOUT_UNALIGNED_ROWS or X.dtype != torch.float64 or N == 0 or D <= 80:
+    if X.dtype == torch.float32 and D <= 128:
+        return X                      # the fp32 mode's resident kernels take any 4-byte aligned rows
+    if not RELAYOUT_UNALIGNED_ROWS or N == 0 or D <= 80:
         return X
-    if X.stride(0) % 2 == 0 and X.data_ptr() % 16 == 0:
+    per16 = 16 // X.element_size()    # elements per 16-byte LDS-DMA lane (float rows of the fp32 mode at D > 128: 4)
+    if X.stride(0) % per16 == 0 and X.data_ptr() % 16 == 0:
         return X
-    Dp = D + (D & 1)
+    Dp = (D + per16 - 1) // per16 * per16
     free, _ = torch.cuda.mem_get_info(X.device)
-    if 2 * N * Dp * 8 > free:
+    if 2 * N * Dp * X.element_size() > free:
         return X
     buf = torch.empty((N, Dp), dtype=X.dtype, device=X.device)
     buf[:, :D] = X
@@ -86,8 +89,9 @@ class WeightedGLMObjective(RegisteredObjective):
 
     ``dtype=torch.float32`` selects the fp32 STORAGE mode (BASELINE.json north_star: optional, 1e-4
     against the fp64 oracle, never the headline): X is kept -- and the sensitivity matrix returned -- in
-    float, half the HBM bytes; theta, y, w, r, d, H, g and the Cholesky factor stay double.  D <= 128 for the
-    Hessian / sensitivity, D <= 4096 for the row operators (gradient, HVP, value)."""
+    float, half the HBM bytes; theta, y, w, r, d, H, g and the Cholesky factor stay double.  D <= 4096 (the row
+    operators' limit): up to 128 the f32-MFMA resident kernels, beyond the tiled kernels on float panels with fp64
+    products and a slab-wise fp64 solve (configs[2]'s D = 1000 with X and S at half the footprint)."""
 
     def __init__(self, X, y, family="logistic", prior=None, scale=1.0, offset=None,
                  device=None, process_group=None, dtype=torch.float64):
@@ -155,7 +159,7 @@ class WeightedGLMObjective(RegisteredObjective):
             self.N, self.D)
         if nbytes == 0:
             raise _lib.VittlesHipError("vt_glm_hessian%s does not support D = %d"
-                                       % ("_f32 (fp32 mode: D <= 128)" if f32 else "", self.D))
+                                       % ("_f32 (fp32 mode: D <= 4096)" if f32 else "", self.D))
         # scratch per stream: two streams driving one objective never share it
         skey = dev.stream_ptr()
         if self._ws is None:
