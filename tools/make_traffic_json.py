@@ -17,7 +17,7 @@ def peak(path, counter, kernel):
 fetch, write, rnd = sys.argv[1:4]
 N, D = 1_000_000, 100
 cmd = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 --warmup 2 "
-       "--no-cpu-baseline --no-hvp --no-block --no-fp32")
+       "--no-cpu-baseline --no-hvp --no-block --no-fp32 --no-c3")
 out = {"workload": {"rows": N, "dim": D}, "command": cmd}
 for kern, alg, note in (("k_trsm_rows_small", 16.0 * N * D + 8.0 * N, "16ND + 8N"),
                         ("k_glm_hess_tile", 8.0 * N * D + 24.0 * N + 8.0 * D * D, "8ND + 24N + 8D^2")):

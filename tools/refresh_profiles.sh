@@ -2,10 +2,10 @@
 # Copy the summaries of gpurun_out/prof (made by tools/collect_profiles.cmd on the GPU box) into profiles/.
 # usage: ROUND=r02 bash tools/refresh_profiles.sh
 cd "$(dirname "$0")/.."
-P=${ROUND:-r02}
+P=${ROUND:-r03}
 newest() { ls -t gpurun_out/prof/$1/*/*$2 | head -1; }
 clean() { grep -v "rocprofv3\|output_stream\|tool.cpp\|amdgpu.ids" "$1"; }
-SIDE="--no-cpu-baseline --no-hvp --no-block --no-fp32"
+SIDE="--no-cpu-baseline --no-hvp --no-block --no-fp32 --no-c3"
 cp gpurun_out/prof/bench.json profiles/${P}_bench.json
 cp $(newest bench_trace kernel_stats.csv) profiles/${P}_bench_kernel_stats.csv
 cp $(newest hvp_trace kernel_stats.csv) profiles/${P}_hvp_kernel_stats.csv
@@ -31,3 +31,10 @@ cp gpurun_out/prof/mfma_f32_valu_overlap.txt profiles/${P}_mfma_f32_valu_overlap
 { echo "# rocprofv3 --pmc SQ_* (one pass), python3 tools/time_hess32.py 100  (fp32 storage mode, N = 10^6, D = 100)"
   python3 tools/pmc_summary.py $(newest pmc_sq32 counter_collection.csv) k_; } > profiles/${P}_pmc_sq_fp32.txt
 python3 tools/make_traffic_json.py $(newest pmc_fetch counter_collection.csv) $(newest pmc_write counter_collection.csv) ${P} > profiles/${P}_traffic.json
+cp $(newest mid_trace kernel_stats.csv) profiles/${P}_mid_d_kernel_stats.csv
+clean gpurun_out/prof/mid.log > profiles/${P}_mid_d_stages.txt
+clean gpurun_out/prof/hvp_multi.txt > profiles/${P}_hvp_multi_stages.txt
+{ echo "# rocprofv3 --pmc FETCH_SIZE and --pmc TCC_HIT_sum TCC_MISS_sum (separate passes), python3 tools/time_syrk_only.py 1250000 1000"
+  echo "# FETCH_SIZE in KB per dispatch, x2 on gfx950 for 16-B/lane LDS-DMA reads; round 2 (tile-major workgroup order): 4.09e7 KB raw = 82 GB, hit rate 2 %"
+  python3 tools/pmc_summary.py $(newest syrk_fetch counter_collection.csv) k_syrk_lds
+  python3 tools/pmc_summary.py $(newest syrk_hit counter_collection.csv) k_syrk_lds; } > profiles/${P}_pmc_syrk_l2.txt
