@@ -41,7 +41,8 @@ def test_potrf_large_not_positive_definite():
 
 
 @pytest.mark.parametrize("N,D,family", [(3000, 130, "logistic"), (5000, 257, "gaussian"), (20000, 1000, "logistic"),
-                                         (1501, 1001, "poisson"), (4200, 301, "logistic")])
+                                         (1501, 1001, "poisson"), (4200, 301, "logistic"),
+                                         (2600, 2100, "logistic")])      # 153 tiles: the plan without the XCD split
 def test_sensitivity_large_d(N, D, family, relerr):
     from oracle import glm
     import vittles_amd as va

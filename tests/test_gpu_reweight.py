@@ -13,7 +13,7 @@ TOL = 1e-10
 
 @pytest.mark.parametrize("N,Da,Db", [(1, 1, 1), (5, 3, 2), (1000, 7, 20), (4099, 64, 100), (3000, 100, 64),
                                      (2049, 130, 100), (777, 128, 257), (5001, 33, 9), (4096, 16, 1000),
-                                     (100000, 200, 100)])
+                                     (100000, 200, 100), (1500, 1500, 1400)])   # last: 132 tiles, no XCD split
 @pytest.mark.parametrize("scaled", [False, True])
 def test_gemm_tn(N, Da, Db, scaled, relerr):
     import torch

@@ -349,11 +349,15 @@ int gemm_nt(double* C, int64_t ldc, int64_t M, int N, const double* A, int64_t l
 //   Workgroup b = slab b:  x = b & 7, j = b >> 3 in [0, per_xcd);  class c owns j in [off[c], off[c] + n[c] s[c]),
 //   sub-range k = (j - off[c]) / n[c], tile (j - off[c]) % n[c]  (sub-range-major: neighbours in time share rows).
 // The two-operand product (GEN) is one class of nta x ntb rectangular tiles.
+// nx = 8: the row partition over the XCDs described above; nx = 1 (more tiles than an XCD has resident slots, so a
+// tile's workgroups cannot be co-resident anyway): every tile splits ALL the rows, one slab per tile and sub-range
+// instead of eight (D = 8192: 2080 slabs of 128 KB, not 16 640).
 struct SyrkPlan {
     int n[4];
     int s[4];
     int off[4];
     int per_xcd;
+    int nx;
 };
 
 struct SyrkArgs {
@@ -364,7 +368,7 @@ struct SyrkArgs {
     int D;
     int nt;        // tiles per side
     SyrkPlan plan;
-    double* part;  // [8 plan.per_xcd][128*128]
+    double* part;  // [plan.nx plan.per_xcd][128*128]
     // GEN (two-operand) mode:  C = X^T diag(d) B  with B (N x Db); nt x ntb rectangular tile grid
     const void* B;   // double, or float for the fp32 storage mode's S (k_syrk_*<true, ..., float>)
     int64_t ldb;
@@ -375,13 +379,13 @@ struct SyrkArgs {
 // workgroup -> (class, tile within the class) and its rows [r0, r1) (multiples of 16 but for the very end)
 __host__ __device__ __forceinline__ void plan_locate(const SyrkPlan& p, int64_t N, int wg, int& cls, int& local,
                                                      int64_t& r0, int64_t& r1) {
-    const int x = wg & 7, j = wg >> 3;
+    const int x = wg % p.nx, j = wg / p.nx;
     cls = 0;
     while (cls < 3 && j >= p.off[cls] + p.n[cls] * p.s[cls]) ++cls;
     const int r = j - p.off[cls];
     const int k = r / p.n[cls];
     local = r - k * p.n[cls];
-    const int64_t len8 = ((N + 7) / 8 + 15) / 16 * 16;
+    const int64_t len8 = ((N + p.nx - 1) / p.nx + 15) / 16 * 16;
     const int64_t x0 = min((int64_t)x * len8, N), x1 = min(N, x0 + len8);
     const int64_t per = ((x1 - x0 + p.s[cls] - 1) / p.s[cls] + 15) / 16 * 16;
     r0 = min(x1, x0 + (int64_t)k * per);
@@ -663,9 +667,10 @@ __global__ __launch_bounds__(256) void k_syrk_reduce(const double* part, int nt,
 #pragma unroll
     for (int x = 0; x < 8; ++x) sx[x] = 0.0;
     for (int k = 0; k < plan.s[cls]; ++k) {
-        const double* p = part + (int64_t)(8 * (plan.off[cls] + k * plan.n[cls] + local)) * (kT * kT) + e;
+        const double* p = part + (int64_t)(plan.nx * (plan.off[cls] + k * plan.n[cls] + local)) * (kT * kT) + e;
 #pragma unroll
-        for (int x = 0; x < 8; ++x) sx[x] += p[(int64_t)x * (kT * kT)];
+        for (int x = 0; x < 8; ++x)
+            if (x < plan.nx) sx[x] += p[(int64_t)x * (kT * kT)];
     }
     double s = ((sx[0] + sx[1]) + (sx[2] + sx[3])) + ((sx[4] + sx[5]) + (sx[6] + sx[7]));
     if (i == j && prior) s += prior[i];
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(256) void k_syrk_reduce(const double* part, int nt,
 // C[i][j] = alpha * sum_chunks part + bias[j]   (i < Da, j < Db): the two-operand product's epilogue.
 // One thread per output element (a single tile may be split 512 ways: 64 MB of slabs), slabs summed
 // in a fixed order.
-__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const double* part, int ntb, int ntl, int nsub, int Da,
+__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const double* part, int ntb, int ntl, int nsub, int nx, int Da,
                                                         int Db, double alpha, const double* bias, double* C,
                                                         int64_t ldc) {
     const int t = blockIdx.y, ti = t / ntb, tj = t - ti * ntb;
@@ -688,9 +693,10 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reduce(const double* part, int 
 #pragma unroll
     for (int x = 0; x < 8; ++x) sx[x] = 0.0;
     for (int k = 0; k < nsub; ++k) {
-        const double* p = part + (int64_t)(8 * (k * ntl + t)) * (kT * kT) + e;
+        const double* p = part + (int64_t)(nx * (k * ntl + t)) * (kT * kT) + e;
 #pragma unroll
-        for (int x = 0; x < 8; ++x) sx[x] += p[(int64_t)x * (kT * kT)];
+        for (int x = 0; x < 8; ++x)
+            if (x < nx) sx[x] += p[(int64_t)x * (kT * kT)];
     }
     double s = alpha * (((sx[0] + sx[1]) + (sx[2] + sx[3])) + ((sx[4] + sx[5]) + (sx[6] + sx[7])));
     if (bias) s += bias[j];
@@ -874,8 +880,12 @@ int vt_large_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, co
     return vt_launch_status();
 }
 
+constexpr int kXcds = 8;
+static int plan_nx(int ntl) { return ntl <= 2 * (2 * num_cu() / kXcds) ? kXcds : 1; }   // two rounds of an XCD's slots
+
 static SyrkPlan uniform_plan(int ntl, int nsub) {   // one class: every tile splits each XCD's rows nsub ways
     SyrkPlan p{};
+    p.nx = plan_nx(ntl);
     p.n[0] = ntl;
     for (int c = 0; c < 4; ++c) p.s[c] = nsub;
     p.off[1] = p.off[2] = p.off[3] = p.per_xcd = ntl * nsub;
@@ -886,18 +896,19 @@ static SyrkPlan uniform_plan(int ntl, int nsub) {   // one class: every tile spl
 // proportion to n_c cost_c.  The launch must FIT whole rounds -- one workgroup too many starts another round, as
 // long as the first -- so shares are rounded down and the class with the most work per workgroup then gets one
 // more sub-range per tile while the whole still fits.
-static SyrkPlan syrk_plan_for(int D, int64_t N, int target, int& maxper_out, const int (&cost)[4]) {
+static SyrkPlan syrk_plan_for(int D, int64_t N, int nx, int target, int& maxper_out, const int (&cost)[4]) {
     const int nt = (D + kT - 1) / kT, wl = D - (nt - 1) * kT;
     const bool partial = wl < kT;
     const int nfull = partial ? nt - 1 : nt;
     SyrkPlan p{};
+    p.nx = nx;
     p.n[0] = nfull * (nfull - 1) / 2;
     p.n[1] = nfull;
     p.n[2] = partial ? nt - 1 : 0;
     p.n[3] = partial ? 1 : 0;
     double W = 0.0;
     for (int c = 0; c < 4; ++c) W += (double)p.n[c] * cost[c];
-    const int64_t max_sub = std::max<int64_t>(1, (N / 8 + 4 * kKC - 1) / (4 * kKC));   // at least 4 stages per workgroup
+    const int64_t max_sub = std::max<int64_t>(1, (N / nx + 4 * kKC - 1) / (4 * kKC));   // at least 4 stages per workgroup
     int wg = 0;
     for (int c = 0; c < 4; ++c) {
         p.s[c] = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)(target * (double)cost[c] / W), max_sub));
@@ -937,13 +948,15 @@ static SyrkPlan syrk_plan(int D, int64_t N) {
     const int nt = (D + kT - 1) / kT, wl = D - (nt - 1) * kT;
     const int cost[4] = {syrk_tile_cost(false, kT, kT), syrk_tile_cost(true, kT, kT), syrk_tile_cost(false, wl, kT),
                          syrk_tile_cost(true, wl, wl)};
-    const int slots = 2 * num_cu() / 8;
+    const int ntl = nt * (nt + 1) / 2;
+    const int nx = plan_nx(ntl);
+    const int slots = 2 * num_cu() / nx;
     SyrkPlan best{};
     double best_est = 0.0;
     for (int r = 1; r <= kSyrkMaxRounds; ++r) {
         if (rounds_env > 0 && r != std::min(rounds_env, kSyrkMaxRounds)) continue;
         int maxper;
-        const SyrkPlan p = syrk_plan_for(D, N, r * slots, maxper, cost);
+        const SyrkPlan p = syrk_plan_for(D, N, nx, r * slots, maxper, cost);
         double W = 0.0;
         for (int c = 0; c < 4; ++c) W += 1000.0 * p.n[c] * cost[c];
         // one round: as long as its heaviest workgroup; more: the mean load of a slot plus half a workgroup of tail
@@ -959,7 +972,7 @@ static SyrkPlan syrk_plan(int D, int64_t N) {
 size_t vt_large_syrk_ws_bytes(int D) {
     const int nt = (D + kT - 1) / kT, ntl = nt * (nt + 1) / 2;
     // a plan fits kSyrkMaxRounds rounds of the chip unless every tile is already unsplit
-    return (size_t)std::max(kSyrkMaxRounds * 2 * num_cu(), 8 * ntl) * kT * kT * sizeof(double);
+    return (size_t)std::max(kSyrkMaxRounds * 2 * num_cu(), plan_nx(ntl) * ntl) * kT * kT * sizeof(double);
 }
 
 template <typename AT>
@@ -978,11 +991,11 @@ static int large_syrk_impl(const AT* X, int64_t ldx, const double* d, int64_t N,
             vt_allow_big_lds((const void*)k_syrk_lds<false, 2, double, AT>, attr[1], (int)shmem) != VT_OK)
             return VT_ERR_HIP;
         if (large_stages() == 2)
-            hipLaunchKernelGGL((k_syrk_lds<false, 2, double, AT>), dim3(8 * plan.per_xcd), dim3(512), shmem, st, a);
+            hipLaunchKernelGGL((k_syrk_lds<false, 2, double, AT>), dim3(plan.nx * plan.per_xcd), dim3(512), shmem, st, a);
         else
-            hipLaunchKernelGGL((k_syrk_lds<false, 3, double, AT>), dim3(8 * plan.per_xcd), dim3(512), shmem, st, a);
+            hipLaunchKernelGGL((k_syrk_lds<false, 3, double, AT>), dim3(plan.nx * plan.per_xcd), dim3(512), shmem, st, a);
     } else {
-        hipLaunchKernelGGL((k_syrk_tile<false, double, AT>), dim3(8 * plan.per_xcd), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_syrk_tile<false, double, AT>), dim3(plan.nx * plan.per_xcd), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(k_syrk_reduce, dim3(kT * kT / 256, ntl), dim3(256), 0, st, (const double*)ws, nt, plan, D, prior,
                        H, ldh);
@@ -1004,11 +1017,11 @@ int vt_large_syrk_f32(const float* X, int64_t ldx, const double* d, int64_t N, i
 // kernels with a second operand and a rectangular tile grid; the N axis is split so that the
 // grid fills the chip even when there is a single output tile.
 // (sub-ranges of an XCD's rows per tile: one round of the XCD's 64 resident workgroups when the tiles are fewer)
-static int gemm_tn_split(int ntl) { return std::max(1, (2 * num_cu() / 8) / ntl); }
+static int gemm_tn_split(int ntl) { return std::max(1, (2 * num_cu() / plan_nx(ntl)) / ntl); }
 
 static size_t gemm_tn_ws_bytes(int Da, int Db) {
     const int nta = (Da + kT - 1) / kT, ntb = (Db + kT - 1) / kT;
-    return (size_t)8 * gemm_tn_split(nta * ntb) * nta * ntb * kT * kT * sizeof(double);
+    return (size_t)plan_nx(nta * ntb) * gemm_tn_split(nta * ntb) * nta * ntb * kT * kT * sizeof(double);
 }
 
 extern "C" size_t vt_gemm_tn_workspace_bytes(int Da, int Db) {
@@ -1027,7 +1040,8 @@ static int gemm_tn_impl(const double* A, int64_t lda, int Da, const BT* B, int64
     hipStream_t st = (hipStream_t)stream;
     const int nta = (Da + kT - 1) / kT, ntb = (Db + kT - 1) / kT, ntl = nta * ntb;
     int ks = gemm_tn_split(ntl);   // sub-ranges per XCD
-    const int64_t nsteps = (N / 8 + 4 * kKC - 1) / (4 * kKC);   // at least 4 stages per workgroup
+    const int nx = plan_nx(ntl);
+    const int64_t nsteps = (N / nx + 4 * kKC - 1) / (4 * kKC);   // at least 4 stages per workgroup
     if (ks > nsteps) ks = (int)std::max<int64_t>(1, nsteps);
     SyrkArgs a{A, lda, rowscale, N, Da, nta, uniform_plan(ntl, ks), (double*)ws, B, ldb, Db, ntb};
     constexpr int kBPer16 = 16 / (int)sizeof(BT);   // B elements per 16-byte DMA lane
@@ -1039,13 +1053,13 @@ static int gemm_tn_impl(const double* A, int64_t lda, int Da, const BT* B, int64
         if (vt_allow_big_lds((const void*)k_syrk_lds<true, 3, BT>, attr[0], (int)shmem) != VT_OK ||
             vt_allow_big_lds((const void*)k_syrk_lds<true, 2, BT>, attr[1], (int)shmem) != VT_OK)
             return VT_ERR_HIP;
-        if (large_stages() == 2) hipLaunchKernelGGL((k_syrk_lds<true, 2, BT>), dim3(8 * ntl * ks), dim3(512), shmem, st, a);
-        else hipLaunchKernelGGL((k_syrk_lds<true, 3, BT>), dim3(8 * ntl * ks), dim3(512), shmem, st, a);
+        if (large_stages() == 2) hipLaunchKernelGGL((k_syrk_lds<true, 2, BT>), dim3(nx * ntl * ks), dim3(512), shmem, st, a);
+        else hipLaunchKernelGGL((k_syrk_lds<true, 3, BT>), dim3(nx * ntl * ks), dim3(512), shmem, st, a);
     } else {
-        hipLaunchKernelGGL((k_syrk_tile<true, BT>), dim3(8 * ntl * ks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_syrk_tile<true, BT>), dim3(nx * ntl * ks), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3(kT * kT / 256, ntl), dim3(256), 0, st, (const double*)ws, ntb, ntl, ks,
-                       Da, Db, alpha, bias, C, ldc);
+                       nx, Da, Db, alpha, bias, C, ldc);
     return vt_launch_status();
 }
 
