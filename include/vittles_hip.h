@@ -254,8 +254,10 @@ int    vt_glm_value(int family, const double* X_dev, int64_t ldx, const double* 
  * kernels multiply in f32 (v_mfma_f32_16x16x4_f32), vt_glm_hessian_f32 also takes its row dot x_n . theta in f32
  * (its r, d, g are f32-accurate, ~1e-6: use vt_glm_grad_f32 / vt_glm_link_f32 where fp64 sums matter, e.g. an
  * optimiser's stopping test) and folds its f32 accumulators into fp64 every <= 4096 rows per wave.
- * D <= VT_SMALL_D_MAX for the Hessian / TRSM, D <= 4096 for the row operators;
- * anything larger returns VT_ERR_UNSUPPORTED (use the fp64 entry points).  Each entry point replaces the same
+ * D <= VT_SMALL_D_MAX for the f32-MFMA Hessian / TRSM kernels (beyond: the tiled route below, D <= 4096).  Row
+ * operators: D <= 4096 when D and ldx are even and X is 8-byte aligned (two floats per lane), D <= 2048 otherwise
+ * (odd D, odd ldx or a 4-byte aligned base take the scalar configurations); anything larger returns
+ * VT_ERR_UNSUPPORTED (use the fp64 entry points).  Each entry point replaces the same
  * reference lines as its fp64 namesake above and takes the same arguments, with float where noted. */
 size_t vt_glm_hessian_f32_workspace_bytes(int64_t N, int D);
 int    vt_glm_hessian_f32(int family, const float* X_dev, int64_t ldx, const double* theta_dev,

@@ -7,6 +7,9 @@
 #ifndef VT_PABL
 #define VT_PABL 0   // dev-only compile-time ablation mask
 #endif
+#ifndef VT_TRSM_PF_ALL
+#define VT_TRSM_PF_ALL 0   // dev-only: force the prefetch depth of the solve kernel for every NB (0 = by NB)
+#endif
 
 namespace {
 
@@ -456,18 +459,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
 #pragma unroll
     for (int r = 0; r < TrsmState<NB, KL, LASTPERM>::NSET; ++r) st.slane[r] = (lane & 48) | (4 * r + (lane & 3));
 
-    f64x4 Gn[NB];  // next tile's right-hand side (prefetch)
-    double coefn;
+    // Right-hand sides of the next PF tiles (prefetch ring, Gn[0] = the next one).  Narrow designs are HBM-bound and a
+    // 16-row tile is only 128 NB bytes per lane group: one tile ahead leaves 20 KB in flight per CU at NB = 2, so
+    // they look further ahead (NB <= 2: 3 tiles, NB <= 4: 2) -- the registers are there.
+    constexpr int PF = VT_TRSM_PF_ALL ? VT_TRSM_PF_ALL : (NB <= 2 ? 3 : NB <= 4 ? 2 : 1);
+    f64x4 Gn[PF][NB];
+    double coefn[PF];
 
     // Unconditional loads with clamped indices (no branch per load): rows past N
     // re-read row N-1 and are zeroed through coef = 0.
-    auto load_group = [&](int64_t grp) {
+    auto load_group = [&](int64_t grp, f64x4 (&G)[NB], double& coef) {
         int64_t row = grp * 16 + n;
         bool rowok = row < a.N;
         int64_t rowc = rowok ? row : a.N - 1;
         const double* br = a.B + rowc * a.ldb;
         double sc = a.rowscale ? a.rowscale[rowc] : 1.0;
-        coefn = rowok ? a.alpha * sc : 0.0;
+        coef = rowok ? a.alpha * sc : 0.0;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             f64x4 v = {0.0, 0.0, 0.0, 0.0};
@@ -489,29 +496,35 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
                     }
                 }
             }
-            Gn[b] = v;
+            G[b] = v;
         }
     };
 
     constexpr bool PREFETCH = WAVES <= 8;   // more waves per SIMD: no register room for (nor need of) a prefetched tile
     int64_t grp = gw;
-    if (PREFETCH && grp < ngroups) load_group(grp);
-    {   // the pack -> LDS, behind the first tile's loads
+    const int64_t last = ngroups - 1;       // (groups past the end re-read the last one: loaded, never used)
+    if constexpr (PREFETCH) {
+#pragma unroll
+        for (int f = 0; f < PF; ++f) load_group(min(grp + f * W, last), Gn[f], coefn[f]);
+    }
+    {   // the pack -> LDS, behind the first tiles' loads
         const f64x2u* src = (const f64x2u*)a.pack;
         f64x2u* dst = (f64x2u*)lds;
         for (int i = threadIdx.x; i < NBT * 256; i += WAVES * 64) dst[i] = src[i];
     }
     __syncthreads();
-    for (; grp < ngroups; grp += W) {
-        if constexpr (!PREFETCH) load_group(grp);
+    // one tile: its right-hand side leaves the ring slot, the slot is refilled PF tiles ahead at once (the ring is
+    // walked by UNROLLING, not by moving registers: a move would wait for the load it moves)
+    auto tile = [&](int64_t g, f64x4 (&G)[NB], double& coef) {
+        if constexpr (!PREFETCH) load_group(g, G, coef);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) st.V[b] = Gn[b] * coefn;
-        int64_t row = grp * 16 + n;
+        for (int b = 0; b < NB; ++b) st.V[b] = G[b] * coef;
+        if constexpr (PREFETCH) load_group(min(g + PF * W, last), G, coef);
+        int64_t row = g * 16 + n;
         const bool rowok = row < a.N;
         st.store_fwd = rowok && a.mode == 1;
         st.store_bwd = rowok && a.mode != 1;
         st.orow = a.Out + (rowok ? row : 0) * a.ldo;
-        if constexpr (PREFETCH) load_group(grp + W < ngroups ? grp + W : grp);
         if (a.mode != 2) {   // forward substitution  L Y = G
             trsm_fetch<0, NB, KL, LASTPERM>(st, st.cur);
             trsm_chain<0, NBT, NB, KL, LASTPERM>(st);
@@ -519,6 +532,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
         if (a.mode != 1) {   // backward substitution  L^T Z = Y
             trsm_fetch<NBT, NB, KL, LASTPERM>(st, st.cur);
             trsm_chain<NBT, 2 * NBT, NB, KL, LASTPERM>(st);
+        }
+    };
+    while (grp < ngroups) {
+#pragma unroll
+        for (int f = 0; f < PF; ++f) {
+            if (grp < ngroups) {
+                tile(grp, Gn[f], coefn[f]);
+                grp += W;
+            }
         }
     }
 }

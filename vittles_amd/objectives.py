@@ -89,8 +89,8 @@ class WeightedGLMObjective(RegisteredObjective):
 
     ``dtype=torch.float32`` selects the fp32 STORAGE mode (BASELINE.json north_star: optional, 1e-4
     against the fp64 oracle, never the headline): X is kept -- and the sensitivity matrix returned -- in
-    float, half the HBM bytes; theta, y, w, r, d, H, g and the Cholesky factor stay double.  D <= 4096 (the row
-    operators' limit): up to 128 the f32-MFMA resident kernels, beyond the tiled kernels on float panels with fp64
+    float, half the HBM bytes; theta, y, w, r, d, H, g and the Cholesky factor stay double.  D <= 4096 for even D
+    (the row operators' limit; odd D: 2048): up to 128 the f32-MFMA resident kernels, beyond the tiled kernels on float panels with fp64
     products and a slab-wise fp64 solve (configs[2]'s D = 1000 with X and S at half the footprint)."""
 
     def __init__(self, X, y, family="logistic", prior=None, scale=1.0, offset=None,
