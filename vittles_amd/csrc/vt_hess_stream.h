@@ -297,10 +297,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_glm_hess_stream(HessStreamArgs<T
 // lanes n and n + 32 each take half of row n's dot (one cross-lane add); both link the row, lane n stores.
 // NB = 5 (D <= 80): 16 rows, four lanes per row; beyond that one wave cannot hold the whole triangle (NBT * 8
 // accumulator registers) at two waves per SIMD, which is what the tile kernel of vt_hessian.hip is for.
+#ifndef VT_RL_RPW12
+#define VT_RL_RPW12 64   // rows per wave and iteration of the row-link kernel for NB <= 2 (dev switch)
+#endif
 struct RowLinkLds {   // offsets in doubles; the tiles hold T (esz = sizeof(T))
     int slab, gsum, theta, waves, per_wave, ts, total;
     __host__ __device__ RowLinkLds(int NB, int esz) {
-        const int RPW = NB <= 2 ? 64 : (NB <= 4 ? 32 : 16);
+        const int RPW = NB <= 2 ? VT_RL_RPW12 : (NB <= 4 ? 32 : 16);
         const int NBT = NB * (NB + 1) / 2;
         slab = 0;
         gsum = NBT * 256;
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(512) void k_glm_hess_rowlink(HessStreamArgs<T> a) {
     constexpr int NBT = NB * (NB + 1) / 2;
     constexpr int L = NBT * 256 + NB * 16;
     constexpr int TS = 16 * NB + 1;
-    constexpr int RPW = NB <= 2 ? 64 : (NB <= 4 ? 32 : 16);     // rows per wave and iteration
+    constexpr int RPW = NB <= 2 ? VT_RL_RPW12 : (NB <= 4 ? 32 : 16);     // rows per wave and iteration
     constexpr int KS = RPW / 4;                // k-steps per iteration
     constexpr int HALVES = 64 / RPW;           // lanes sharing a row's dot
     constexpr int CPL = 16 * NB / HALVES;      // columns per lane in the dot
@@ -541,10 +544,10 @@ int rl_launch(const HessStreamArgs<T>& a, int grid, hipStream_t st) {
 }
 
 // rows per wave and iteration of the row-link kernel, and its grid for N rows on cu compute units
-inline int rl_rows_per_wave(int NB) { return NB <= 2 ? 64 : (NB <= 4 ? 32 : 16); }
-inline int rl_grid(int64_t N, int NB, int cu) {
+inline int rl_rows_per_wave(int NB) { return NB <= 2 ? VT_RL_RPW12 : (NB <= 4 ? 32 : 16); }
+inline int rl_grid(int64_t N, int NB, int cu, int wgs_per_cu = 1) {
     const int64_t nsg = (N + rl_rows_per_wave(NB) - 1) / rl_rows_per_wave(NB);
-    return (int)std::max<int64_t>(1, std::min<int64_t>((nsg + 7) / 8, cu));
+    return (int)std::max<int64_t>(1, std::min<int64_t>((nsg + 7) / 8, (int64_t)cu * wgs_per_cu));
 }
 
 inline int hs_slab_len(int NB) { return NB * (NB + 1) / 2 * 256 + NB * 16; }

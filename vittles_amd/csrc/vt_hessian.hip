@@ -915,7 +915,9 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
         // (the row-link kernel addresses 64 rows through one buffer descriptor with 32-bit offsets)
         if (!no_rowlink && ldx <= ((int64_t)1 << 22)) {
             // super-groups of 64 (NB <= 2) or 32 rows, one 8-wave workgroup per CU
-            const int rgrid = rl_grid(N, NB, num_cu());
+            static const int rl_wgs_env = getenv("VT_RL_WGS") ? atoi(getenv("VT_RL_WGS")) : 0;   // dev switch
+            const int rl_wgs = rl_wgs_env > 0 ? std::min(rl_wgs_env, 4) : 1;
+            const int rgrid = rl_grid(N, NB, num_cu(), rl_wgs);
             switch (NB) {
                 case 1: rc = rl_launch<double, 1>(sa, rgrid, st); break;
                 case 2: rc = rl_launch<double, 2>(sa, rgrid, st); break;
