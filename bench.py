@@ -863,6 +863,27 @@ def main():
             "host_regenerated_rows": int(len(ridx)),
             "X_max_abs_diff_vs_host": float(np.abs(X[torch.as_tensor(ridx, device=device)].cpu().numpy() - Xr).max()),
             "y_mismatches_vs_host": int((y[torch.as_tensor(ridx, device=device)].cpu().numpy() != yr).sum())}
+        if world == 1:
+            # what this box streams with torch's own kernels on arrays of the solve's size (context for `hbm_GBs`: the
+            # dominant kernel reads X and writes S, a device copy is the same traffic with no arithmetic)
+            def _rate(fn, nbytes, reps=20):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record()
+                for _ in range(reps):
+                    fn()
+                a1.record()
+                torch.cuda.synchronize()
+                return nbytes / (a0.elapsed_time(a1) / reps * 1e-3) / 1e9
+            _tmp = torch.empty_like(S)
+            result["roofline"]["stream_reference"] = {
+                "device_copy_GBs_read_plus_write": _rate(lambda: _tmp.copy_(X), 16.0 * N * D),
+                "read_only_sum_GBs": _rate(lambda: X.sum(), 8.0 * N * D),
+                "note": "torch copy / sum of the same N x D arrays on this box, measured after the timed region: the "
+                        "solve's read + write stream (hbm_GBs) against what a plain copy reaches"}
+            del _tmp
         if world == 1:   # side measurements and CPU legs run at N=1 only: no rank waits on rank 0
             if not args.no_cpu_baseline:
                 n_s = min(args.cpu_rows, N)
