@@ -87,6 +87,12 @@ def glm_checks(rank, world, group, family, N, D):
     xd, cinfo, iters = cg_solve(lambda p, o: hvp.apply(p, o), torch.tensor(bvec, device="cuda"), tol=1e-9)
     assert cinfo == info_ref == 0 and abs(iters - it_ref) <= 1
     assert rel(xd.cpu().numpy(), x_ref) < 1e-8
+    # block CG on the sharded objective: K right-hand sides, ONE all-reduce of the K x D partial products per
+    # iteration (multi-vector HVP kernels for K >= 4), every column against the unsharded dense solve
+    Bk = rng.standard_normal((D, 6))
+    Xk = va.solver_lib.get_cg_solver(hvp, D, cg_opts={'tol': 1e-12})(Bk)
+    H_full = glm.hessian(family, X, y, theta_ref, w, prior)
+    assert Xk.shape == (D, 6) and rel(Xk, np.linalg.solve(H_full, Bk)) < 1e-8, rel(Xk, np.linalg.solve(H_full, Bk))
 
     # second-order data-weight terms: partial right-hand sides all-reduced
     te = va.ParametricSensitivityTaylorExpansion.optimization_objective(obj, theta_ref, w[a:b], order=2)
