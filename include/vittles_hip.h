@@ -348,6 +348,15 @@ int    vt_cg_init_multi(const double* b_dev, const double* q0_dev, double* r_dev
 int    vt_cg_update_multi(double* p_dev, const double* q_dev, double* x_dev, double* r_dev, int64_t D,
                           int64_t ld, int K, const double* minv_dev, double* scal_dev, void* stream);
 
+/* Out[k][i] = sum_p data[p] X[k][indices[p]], p in [indptr[i], indptr[i+1]): CSR (int32 indices, fp64 values) times
+ * K vectors stored as the rows of X (K x n, leading dimension ldx), fixed summation order.
+ * Replaces: the solves scipy.sparse.linalg.factorized (SuperLU) does for a GENERAL sparse matrix in
+ *             get_sparse_cholesky_solver (vittles/solver_lib.py:46-48): for a sparse SPD matrix that is neither
+ *             block-arrowhead nor small enough for the dense device Cholesky the Python mirror runs the block CG
+ *             above (Jacobi preconditioner, relative residual 1e-12) over this product. */
+int    vt_spmv_csr(const int* indptr_dev, const int* indices_dev, const double* data_dev, int n,
+                   const double* X_dev, int64_t ldx, int K, double* Out_dev, int64_t ldo, void* stream);
+
 /* out_dev[0] = sum_i a_i b_i c_i  (c_dev NULL: sum_i a_i b_i), one workgroup, fixed summation order.
  * Replaces: the NumPy reductions around the path -- np.linalg.norm of the estimating equation / of the Newton
  *             step (vittles/sensitivity_lib.py:209, vittles/lr_cov_lib.py:112), and the prior term of the

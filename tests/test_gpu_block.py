@@ -263,11 +263,33 @@ def test_sparse_solver_stale_snapshot_and_fallbacks():
     v = rng.standard_normal(300)
     xs = va.solver_lib.get_sparse_cholesky_solver(A)(v)
     assert np.abs(xs - scipy.sparse.linalg.spsolve(A, v)).max() <= 1e-10 * np.abs(xs).max()
-    # unstructured (a chain: one connected component) above the dense limit: a clear error, no todense()
+    # unstructured (a chain: one connected component) above the dense limit: the iterative route (block CG over
+    # vt_spmv_csr, Jacobi preconditioner), never a todense(); the reference hands this to SuperLU (solver_lib.py:46-48)
     n = 9000
     T = scipy.sparse.diags([np.full(n - 1, -1.0), np.full(n, 4.0), np.full(n - 1, -1.0)], [-1, 0, 1]).tocsc()
-    with pytest.raises(VittlesHipError, match="not block-arrowhead"):
-        va.solver_lib.get_sparse_cholesky_solver(T)
+    solveT = va.solver_lib.get_sparse_cholesky_solver(T)
+    vT = rng.standard_normal(n)
+    xT = solveT(vT)
+    assert np.abs(xT - scipy.sparse.linalg.spsolve(T, vT)).max() <= 1e-10 * np.abs(xT).max()
+    VT = rng.standard_normal((n, 5))
+    XT = solveT(VT)
+    assert XT.shape == (n, 5) and np.abs(T @ XT - VT).max() <= 1e-10 * np.abs(VT).max()
+    # a random unstructured SPD pattern with uneven rows and a badly scaled diagonal
+    Rm = scipy.sparse.random(n, n, density=4e-4, random_state=7, format="csr")
+    Rm = Rm + Rm.T
+    Dg = scipy.sparse.diags(np.logspace(0, 3, n))
+    Am = (Dg @ (Rm + scipy.sparse.diags(np.asarray(abs(Rm).sum(axis=1)).ravel() + 1.0)) @ Dg).tocsc()
+    xa = va.solver_lib.get_sparse_cholesky_solver(Am)(vT)
+    assert np.abs(xa - scipy.sparse.linalg.spsolve(Am, vT)).max() <= 1e-9 * np.abs(xa).max()
+    # not symmetric -> ValueError; indefinite -> LinAlgError (no silent poor answer)
+    with pytest.raises(ValueError, match="SYMMETRIC"):
+        va.solver_lib.get_sparse_cholesky_solver(scipy.sparse.triu(T).tocsc())
+    Tind = (T - scipy.sparse.diags(np.where(np.arange(n) % 2 == 0, 6.0, 0.0))).tocsc()
+    with pytest.raises(np.linalg.LinAlgError):
+        va.solver_lib.get_sparse_cholesky_solver(Tind)(vT)
+    Tind2 = (T - 3.9 * scipy.sparse.identity(n)).tocsc()       # positive diagonal, eigenvalues of both signs
+    with pytest.raises(np.linalg.LinAlgError):
+        va.solver_lib.get_sparse_cholesky_solver(Tind2)(vT)
     # ... and a non-SPD block matrix raises LinAlgError (Cholesky only; the reference's SuperLU would take it)
     Hneg = H.copy()
     Hneg.data = -Hneg.data

@@ -62,7 +62,8 @@ def cg_solve_multi(matvec_multi_dev, B, X0=None, tol=1e-5, maxiter=None, minv=No
     it has converged, so each solution is what a single-vector solve returns.  ``matvec_multi_dev(P, Q)`` fills
     ``Q[k] = A P[k]``; ``minv``: the diagonal of a preconditioner M ~ A^{-1} as a (D,) CUDA vector; ``callback(k,
     x_k)`` after every iteration of a still-active column (x_k: a CUDA view).  Returns (X, info (K,), iterations
-    (K,))."""
+    (K,)); info is 0, ``maxiter`` (exhausted, as SciPy reports it) or -1 (breakdown: ``p.Ap <= 0`` -- the operator is
+    not positive definite -- or a non-finite residual; the column is frozen at the iterate before it)."""
     lib = dev.require_gpu()
     K, D = B.shape
     if maxiter is None:
@@ -86,21 +87,28 @@ def cg_solve_multi(matvec_multi_dev, B, X0=None, tol=1e-5, maxiter=None, minv=No
     atol = np.where(rnorm <= tol, np.inf, atol)
     scal[:, 6] = torch.as_tensor(atol, device=B.device)
     info = np.zeros(K, dtype=np.int64)
-    active = rnorm >= atol
+    broken = np.zeros(K, dtype=bool)         # breakdown: p.Ap <= 0 (A is not positive definite) or a non-finite residual
+    active = ~(rnorm < atol)
     for _ in range(maxiter):
-        active = rnorm >= atol
+        active = ~(rnorm < atol) & ~broken
         if not active.any():
             break
         matvec_multi_dev(P, Q)
         _lib.check(lib.vt_cg_update_multi(P.data_ptr(), Q.data_ptr(), X.data_ptr(), R.data_ptr(), D, D, K,
                                           dev.ptr(minv), scal.data_ptr(), st), "vt_cg_update_multi")
-        rnorm = scal[:, 1].cpu().numpy()     # the iteration's only host sync (8 K bytes)
+        h = scal.cpu().numpy()               # the iteration's only host sync (64 K bytes)
+        rnorm = h[:, 1].copy()
+        bad = active & (~np.isfinite(rnorm) | ~(h[:, 3] > 0.0))
+        if bad.any():
+            broken |= bad
+            scal[:, 6] = torch.as_tensor(np.where(broken, np.inf, atol), device=B.device)   # freeze those columns
         if callback is not None:
             for k in np.nonzero(active)[0]:
                 callback(int(k), X[k])
     else:
         # SciPy's for-else: a column that was still iterating in the last pass reports maxiter, converged or not
         info[active] = maxiter
+    info[broken] = -1
     iters = scal[:, 5].cpu().numpy().astype(np.int64)
     return X, info, iters
 

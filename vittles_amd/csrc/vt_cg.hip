@@ -213,3 +213,33 @@ extern "C" int vt_dot3(const double* a, const double* b, const double* c, int64_
     hipLaunchKernelGGL(k_dot3, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, c, n, out);
     return vt_launch_status();
 }
+
+// ---- sparse matrix-vector product (CSR, fp64 values, int32 indices) for K vectors at once ----------------------
+// Out[k][i] = sum_p data[p] X[k][indices[p]],  p in [indptr[i], indptr[i+1]):  16 lanes walk a row, summed by DPP in a
+// fixed order.  The `mat_times_vec` of the iterative route of get_sparse_cholesky_solver for sparse SPD matrices
+// that are neither block-arrowhead nor small enough to densify (the reference hands them to SuperLU,
+// vittles/solver_lib.py:46-48).
+namespace {
+__global__ __launch_bounds__(256) void k_spmv_csr(const int* indptr, const int* indices, const double* data, int n,
+                                                  const double* X, int64_t ldx, double* Out, int64_t ldo) {
+    const int row = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4), c = threadIdx.x & 15;
+    const double* x = X + (int64_t)blockIdx.y * ldx;
+    double s = 0.0;
+    if (row < n) {
+        const int p1 = indptr[row + 1];
+        for (int p = indptr[row] + c; p < p1; p += 16) s = fma(data[p], x[indices[p]], s);
+    }
+    s = vt_sum16(s);
+    if (row < n && c == 0) Out[(int64_t)blockIdx.y * ldo + row] = s;
+}
+}  // namespace
+
+extern "C" int vt_spmv_csr(const int* indptr, const int* indices, const double* data, int n, const double* X,
+                           int64_t ldx, int K, double* Out, int64_t ldo, void* stream) {
+    if (!indptr || !X || !Out || n < 1 || K < 1 || (K > 1 && (ldx < n || ldo < n))) return VT_ERR_BAD_ARG;
+    if (K > 65535) return VT_ERR_UNSUPPORTED;
+    const unsigned gx = (unsigned)(((int64_t)n * 16 + 255) / 256);
+    hipLaunchKernelGGL(k_spmv_csr, dim3(gx, K), dim3(256), 0, (hipStream_t)stream, indptr, indices, data, n, X, ldx, Out,
+                       ldo);
+    return vt_launch_status();
+}
