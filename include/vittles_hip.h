@@ -348,6 +348,22 @@ int    vt_cg_init_multi(const double* b_dev, const double* q0_dev, double* r_dev
 int    vt_cg_update_multi(double* p_dev, const double* q_dev, double* x_dev, double* r_dev, int64_t D,
                           int64_t ld, int K, const double* minv_dev, double* scal_dev, void* stream);
 
+/* ---- multi-GPU: the path's one data-path collective through the C-ABI -------------------------------------------
+ * One process (or thread) per GPU; every rank holds a contiguous row shard of (X, y, w) and calls the entry points
+ * above on it with prior_dev = NULL on every rank but one.  The only exchange of the dense path is the sum
+ * all-reduce of [H | g] (lay them out in one buffer of D*D + pad + D doubles and reduce it in place before
+ * vt_potrf_pack_from; S stays sharded like X), of the CG route the D-vector of vt_glm_hvp (or the K x D block of
+ * vt_glm_hvp_multi) once per iteration.  These four bind RCCL directly (librccl.so is dlopen'ed at the first call;
+ * VT_ERR_UNSUPPORTED if it is not there); the Python mirror uses torch.distributed (backend "nccl" = RCCL) instead.
+ *   vt_comm_unique_id: 128 bytes made on rank 0 (ncclGetUniqueId), handed to the other ranks by the host's own means.
+ *   vt_comm_init     : ncclCommInitRank on the CURRENT device (hipSetDevice first); collective over all ranks.
+ *   vt_allreduce_sum : in place, fp64, on `stream`; ordered with the kernels queued on that stream.
+ * No counterpart in the reference (a single-process NumPy library); SURVEY.md section 8b/8e's `vt_set_comm` hook. */
+int    vt_comm_unique_id(void* id128);
+int    vt_comm_init(void** comm_out, int nranks, int rank, const void* id128);
+int    vt_comm_destroy(void* comm);
+int    vt_allreduce_sum(void* comm, double* buf_dev, int64_t count, void* stream);
+
 /* Out[k][i] = sum_p data[p] X[k][indices[p]], p in [indptr[i], indptr[i+1]): CSR (int32 indices, fp64 values) times
  * K vectors stored as the rows of X (K x n, leading dimension ldx), fixed summation order.
  * Replaces: the solves scipy.sparse.linalg.factorized (SuperLU) does for a GENERAL sparse matrix in

@@ -50,3 +50,17 @@ def test_rccl_world_of_one_matches_unsharded(relerr):
         assert relerr(S, S_ref) < 1e-10
     finally:
         dist.destroy_process_group()
+
+
+def test_c_abi_rccl_binding_world_of_one():
+    """vt_comm_unique_id / vt_comm_init / vt_allreduce_sum / vt_comm_destroy from a torch-free host process (HIP
+    runtime through ctypes, like a C caller): a world of one rank on GPU 0 (tests/_comm_worker.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-u", os.path.join(root, "tests", "_comm_worker.py")], capture_output=True,
+                         text=True, timeout=240)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    if "comm unsupported" in res.stdout:
+        pytest.skip("librccl.so is not on this box")
+    assert "comm ok" in res.stdout

@@ -65,6 +65,10 @@ SIGNATURES = {
     "vt_glm_hvp_multi_workspace_bytes": (c_size_t, [c_i64, c_int, c_int]),
     "vt_glm_hvp_multi": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_dbl, c_ptr, c_i64, c_int, c_i64, c_int, c_ptr, c_i64,
                                  c_ptr, c_size_t, c_ptr]),
+    "vt_comm_unique_id": (c_int, [c_ptr]),
+    "vt_comm_init": (c_int, [ctypes.POINTER(c_ptr), c_int, c_int, c_ptr]),
+    "vt_comm_destroy": (c_int, [c_ptr]),
+    "vt_allreduce_sum": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
     "vt_spmv_csr": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     "vt_dot3": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "vt_vi_workspace_bytes": (c_size_t, [c_int, c_int]),
