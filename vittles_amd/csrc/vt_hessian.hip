@@ -534,7 +534,10 @@ __device__ __forceinline__ void hess_tile_mfma(const HessArgs& a, double* lds, i
     // accumulator slot of an owned block = its rank among the quarter's blocks
     auto slot = [](int ord) constexpr { return __builtin_popcountll(OWN & ((1ull << ord) - 1ull)); };
     constexpr int KSTEPS = TR / 4;
-    constexpr int K0 = KSTEPS / kTileNM;               // wave 0 (which also issues the DMA): 6 of 12, 4 of 9
+#ifndef VT_TILE_K0_DELTA
+#define VT_TILE_K0_DELTA 0   // dev switch: k-steps taken from the DMA-issuing wave and given to the other one(s)
+#endif
+    constexpr int K0 = KSTEPS / kTileNM - VT_TILE_K0_DELTA;   // wave 0 (which also issues the DMA): 6 of 12, 4 of 9
     static_assert((KSTEPS - K0) % (kTileNM - 1) == 0, "k-step split");
     constexpr int KR = (KSTEPS - K0) / (kTileNM - 1);
     constexpr int RPS = TR / 4;
