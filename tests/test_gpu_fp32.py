@@ -191,10 +191,13 @@ def test_fp32_row_operators(relerr):
     from vittles_amd import rows
     import vittles_amd as va
     for (N, D, family) in [(1000, 20, "logistic"), (513, 129, "poisson"), (3000, 1000, "gaussian"),
-                           (257, 31, "logistic"), (64, 4096, "logistic"), (5000, 100, "poisson")]:
+                           (257, 31, "logistic"), (64, 4096, "logistic"), (5000, 100, "poisson"),
+                           # wide float rows (round 3: the wide team on 16-byte lanes): D > 4096, odd widths re-laid
+                           (300, 4100, "logistic"), (257, 10241, "gaussian"), (200, 20000, "logistic"),
+                           (130, 20447, "poisson")]:
         X, y, w, theta, offset = _problem(N, D, family, seed=N + D, with_offset=True)
         if family == "poisson":
-            theta = theta * 0.1
+            theta = theta * (0.1 if D < 4096 else 0.01)
         X32 = X.astype(np.float32).astype(np.float64)
         prior = np.linspace(0.5, 2.0, D)
         obj = va.WeightedGLMObjective(X, y, family=family, prior=prior, scale=0.7, offset=offset,

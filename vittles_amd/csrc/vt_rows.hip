@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
 typedef unsigned vt_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned vt_u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const double* row, unsigned bytes) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void* row, unsigned bytes) {
     uint64_t b = (uint64_t)row;
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
     uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
@@ -284,21 +284,41 @@ struct Chunk<1> {
     __device__ __forceinline__ double get(int) const { return v; }
 };
 
+// fp32 storage mode, wide rows: four floats (16 bytes) per lane and chunk, widened as they are used
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+struct ChunkF4 {
+    f32x4u v;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        v = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 2));
+    }
+    __device__ __forceinline__ double get(int e) const { return (double)v[e]; }
+};
+template <int VEC, typename XT>
+struct ChunkOf { using type = Chunk<VEC>; };
+template <>
+struct ChunkOf<4, float> { using type = ChunkF4; };
+
 constexpr int kWideTeam = 512;
 
-template <int OP, int VEC, int CPT, int P>
+// XT = float: VEC = 4 (the fp32 storage mode's X for D > 4096, e.g. configs[3]'s D = 20000 at half the bytes); v, the
+// accumulators and every sum stay double.
+template <int OP, int VEC, int CPT, int P, typename XT = double>
 __global__ __launch_bounds__(kWideTeam) void k_rows_wide(RowArgs a) {
+    static_assert(std::is_same<XT, double>::value ? VEC <= 2 : VEC == 4, "double: 1 or 2 per lane, float: 4");
     using T = OpTraits<OP>;
+    using ChunkT = typename ChunkOf<VEC, XT>::type;
     constexpr int TW = kWideTeam / 64;
+    constexpr unsigned ES = (unsigned)sizeof(XT);
     extern __shared__ double dyn[];
     const int D = a.D;
-    const int DZ = (D + 1) & ~1;  // a zero pair behind v for lanes past the row end
+    constexpr int ZP = VEC == 4 ? 4 : 2;              // zeros behind v for lanes past the row end: vl[DZ .. DZ + ZP)
+    const int DZ = (D + ZP - 1) / ZP * ZP;
     double* vl = dyn;
-    double* red = dyn + (T::kDot ? DZ + 2 : 0);  // [2][TW]
+    double* red = dyn + (T::kDot ? DZ + ZP : 0);  // [2][TW]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t Tn = gridDim.x, g = blockIdx.x;
-    const unsigned voff = 8u * VEC * tid, rowbytes = 8u * D;
-    constexpr unsigned kStep = 8u * VEC * kWideTeam;
+    const unsigned voff = ES * VEC * tid, rowbytes = ES * D;
+    constexpr unsigned kStep = ES * VEC * kWideTeam;
 
     double acc[T::kCols ? CPT * VEC : 1];
     if constexpr (T::kCols) {
@@ -306,18 +326,18 @@ __global__ __launch_bounds__(kWideTeam) void k_rows_wide(RowArgs a) {
         for (int i = 0; i < CPT * VEC; ++i) acc[i] = 0.0;
     }
     if constexpr (T::kDot) {
-        for (int c = tid; c < DZ + 2; c += kWideTeam) vl[c] = c < D ? a.v[c] : 0.0;
+        for (int c = tid; c < DZ + ZP; c += kWideTeam) vl[c] = c < D ? a.v[c] : 0.0;
         __syncthreads();
     }
     double val = 0.0;
     const int64_t iters = (a.N + Tn - 1) / Tn;
-    Chunk<VEC> x[CPT], q[P];
+    ChunkT x[CPT], q[P];
     RowScal sn;
     __amdgpu_buffer_rsrc_t r;
     {
         bool ok = g < a.N;
         int64_t nc = ok ? g : 0;
-        r = row_rsrc((const double*)a.X + nc * a.ldx, ok ? rowbytes : 0);
+        r = row_rsrc((const XT*)a.X + nc * a.ldx, ok ? rowbytes : 0);
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             if (k < P) q[k].load(r, voff + kStep * k);
@@ -335,7 +355,7 @@ __global__ __launch_bounds__(kWideTeam) void k_rows_wide(RowArgs a) {
             int64_t n1 = n + Tn;
             bool ok = n1 < a.N;
             int64_t nc = ok ? n1 : 0;
-            r = row_rsrc((const double*)a.X + nc * a.ldx, ok ? rowbytes : 0);
+            r = row_rsrc((const XT*)a.X + nc * a.ldx, ok ? rowbytes : 0);
 #pragma unroll
             for (int k = 0; k < P; ++k) q[k].load(r, voff + kStep * k);
             sn = load_scal<OP>(a, nc);
@@ -345,7 +365,12 @@ __global__ __launch_bounds__(kWideTeam) void k_rows_wide(RowArgs a) {
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
                 const int c = VEC * (tid + kWideTeam * k);
-                if constexpr (VEC == 2) {
+                if constexpr (VEC == 4) {
+                    f64x2u v0 = *(const f64x2u*)(vl + min(c, DZ));
+                    f64x2u v1 = *(const f64x2u*)(vl + min(c, DZ) + 2);
+                    dot = fma(x[k].get(0), v0[0], fma(x[k].get(1), v0[1], dot));
+                    dot = fma(x[k].get(2), v1[0], fma(x[k].get(3), v1[1], dot));
+                } else if constexpr (VEC == 2) {
                     f64x2u vk = *(const f64x2u*)(vl + min(c, DZ));
                     dot = fma(x[k].get(0), vk[0], fma(x[k].get(1), vk[1], dot));
                 } else {
@@ -427,7 +452,7 @@ struct RowCfg {
 constexpr int kWideDMax = 20448;
 
 // Pick the smallest team that covers D with the compiled chunk counts.
-bool pick_cfg(int D, bool vec2, RowCfg& c) {
+bool pick_cfg(int D, bool vec2, RowCfg& c, bool float_vec4 = false) {
     const int vec = vec2 ? 2 : 1;
     struct Opt { int team, cpt; };
     static const Opt opts[] = {{16, 1}, {16, 2}, {16, 4}, {64, 2}, {64, 4}, {64, 8}, {256, 4}, {256, 8}};
@@ -438,6 +463,15 @@ bool pick_cfg(int D, bool vec2, RowCfg& c) {
         }
     }
     if (D > kWideDMax) return false;
+    if (float_vec4) {   // float rows on a 16-byte pitch: chunks of four floats, 5 or 10 per lane
+        for (int st : {5, 10}) {
+            if ((int64_t)kWideTeam * st * 4 >= D) {
+                c = RowCfg{kWideTeam, st, 4, kWideTeam, 1};
+                return true;
+            }
+        }
+        return false;
+    }
     // wide team: bytes per lane in steps of 80 (5 x 16 B)
     static const int steps[] = {5, 10, 15, 20};
     for (int st : steps) {
@@ -460,12 +494,13 @@ void launch_one(const RowArgs& a, int grid, bool nt, hipStream_t st) {
     else hipLaunchKernelGGL((k_rows<OP, TEAM, CPT, VEC, 0, XT>), dim3(grid), dim3(WG), shmem, st, a);
 }
 
-template <int OP, int VEC, int CPT, int P>
+template <int OP, int VEC, int CPT, int P, typename XT = double>
 int launch_wide(const RowArgs& a, int grid, hipStream_t st) {
-    size_t shmem = (size_t)8 * (((a.D + 1) & ~1) + 2 + 2 * (kWideTeam / 64));
+    constexpr int ZP = VEC == 4 ? 4 : 2;
+    size_t shmem = (size_t)8 * ((a.D + ZP - 1) / ZP * ZP + ZP + 2 * (kWideTeam / 64));
     static VtLdsAttr attr;  // per instantiation, per device
-    if (vt_allow_big_lds((const void*)k_rows_wide<OP, VEC, CPT, P>, attr, 160 * 1024) != VT_OK) return VT_ERR_HIP;
-    hipLaunchKernelGGL((k_rows_wide<OP, VEC, CPT, P>), dim3(grid), dim3(kWideTeam), shmem, st, a);
+    if (vt_allow_big_lds((const void*)k_rows_wide<OP, VEC, CPT, P, XT>, attr, 160 * 1024) != VT_OK) return VT_ERR_HIP;
+    hipLaunchKernelGGL((k_rows_wide<OP, VEC, CPT, P, XT>), dim3(grid), dim3(kWideTeam), shmem, st, a);
     return VT_OK;
 }
 
@@ -479,7 +514,18 @@ int launch_cfg(const RowArgs& a, const RowCfg& c, int grid, bool nt, hipStream_t
     VT_CASE(16, 1) VT_CASE(16, 2) VT_CASE(16, 4) VT_CASE(64, 2) VT_CASE(64, 4) VT_CASE(64, 8)
     VT_CASE(256, 4) VT_CASE(256, 8)
 #undef VT_CASE
-    if constexpr (std::is_same<XT, double>::value) if (c.team == kWideTeam) {   // wide rows: fp64 storage only
+    if constexpr (std::is_same<XT, float>::value) {
+        // wide float rows (the fp32 mode at D > 4096): four floats per lane and chunk, OP by OP what the mode exposes
+        if (c.team == kWideTeam && c.vec == 4) {
+            if constexpr (OP == OP_LINK || OP == OP_GRAD || OP == OP_HVP || OP == OP_GEMV || OP == OP_GEMVT ||
+                          OP == OP_VALUE) {
+                if (c.cpt == 5) return launch_wide<OP, 4, 5, 5, float>(a, grid, st);
+                if (c.cpt == 10) return launch_wide<OP, 4, 10, (OP == OP_GRAD ? 6 : 10), float>(a, grid, st);
+            }
+        }
+        return VT_ERR_UNSUPPORTED;
+    }
+    if constexpr (std::is_same<XT, double>::value) if (c.team == kWideTeam) {   // wide rows of doubles
         // (chunks, prefetched chunks): full double buffering while the registers allow it
         if constexpr (VEC == 2) {
             if (c.cpt == 5) return launch_wide<OP, 2, 5, 5>(a, grid, st);
@@ -501,8 +547,11 @@ int launch_cfg(const RowArgs& a, const RowCfg& c, int grid, bool nt, hipStream_t
 template <int OP, typename XT = double>
 int run_rows(RowArgs a, hipStream_t st, int max_slabs = 0) {
     bool vec2 = (a.D % 2 == 0) && (a.ldx % 2 == 0) && (((uintptr_t)a.X) % (2 * sizeof(XT)) == 0);
+    // float rows past what the 256-thread teams cover: the wide kernel on 16-byte lanes (rows on a 16-byte pitch)
+    const bool f4 = std::is_same<XT, float>::value && a.D > (vec2 ? 4096 : 2048) && a.ldx % 4 == 0 &&
+                    ((uintptr_t)a.X) % 16 == 0;
     RowCfg c;
-    if (!pick_cfg(a.D, vec2, c)) return VT_ERR_UNSUPPORTED;
+    if (!pick_cfg(a.D, vec2, c, f4)) return VT_ERR_UNSUPPORTED;
     int64_t want = (a.N + c.teams - 1) / c.teams;
     // 512-thread teams: one per CU; 256-thread workgroups: up to 4 per CU.
     int cap = c.wg == kWideTeam ? num_cu() : max_grid();
@@ -510,7 +559,7 @@ int run_rows(RowArgs a, hipStream_t st, int max_slabs = 0) {
     if (max_slabs > 0 && grid > max_slabs) return VT_ERR_SCRATCH_LIMIT;
     // stream X past the caches once it is larger than the Infinity Cache can hold
     bool nt = (double)a.N * a.D * (double)sizeof(XT) > 192.0e6;
-    int rc = vec2 ? launch_cfg<OP, 2, XT>(a, c, grid, nt, st) : launch_cfg<OP, 1, XT>(a, c, grid, nt, st);
+    int rc = (vec2 || c.vec == 4) ? launch_cfg<OP, 2, XT>(a, c, grid, nt, st) : launch_cfg<OP, 1, XT>(a, c, grid, nt, st);
     if (rc != VT_OK) return rc;
     if (hipGetLastError() != hipSuccess) return VT_ERR_HIP;
     return grid;
