@@ -208,6 +208,33 @@ def hvp_cg_side_measurement(torch, device, n_rows, dim, cpu_rows, reps=10):
                "speedup_vs_columns_one_by_one": Kb * gpu_s / blk_s}
     del dW, Bk, Xk, Rk
 
+    # (ii-c) the optional fp32 STORAGE mode on the same rows: X rounded to float (half the bytes per product),
+    # vectors and every sum fp64 -- the wide row kernel on 16-byte lanes of four floats
+    obj32 = va.WeightedGLMObjective(X.to(torch.float32), y, family="logistic", prior=1.0, dtype=torch.float32)
+    hvp32 = cg.GLMHessianVectorProduct(obj32, theta, w)
+    _, r32, _ = rows.glm_link(obj32, theta, w)
+    b32 = rows.gemv_t2(obj32.X, r32, dw)
+    cg.cg_solve(lambda p, q: hvp32.apply(p, q), b32, tol=tol)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        hvp32.apply(v, out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms32 = e0.elapsed_time(e1) / reps
+    times32 = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        x32, info32, iters32 = cg.cg_solve(lambda p, q: hvp32.apply(p, q), b32, tol=tol)
+        torch.cuda.synchronize()
+        times32.append(time.perf_counter() - t0)
+    res_f32 = {"note": "optional mode, never the headline: X stored in float, vectors and every sum fp64",
+               "hvp_ms": ms32, "hvp_GBs": (4.0 * n_rows * dim + 8.0 * n_rows + 16.0 * dim) / (ms32 * 1e-3) / 1e9,
+               "gpu_ms": float(np.median(times32)) * 1e3, "gpu_iterations": int(iters32), "gpu_info": int(info32),
+               "solution_rel_diff_vs_fp64": float(((x32 - x).norm() / x.norm()).item()),
+               "speedup_vs_fp64": gpu_s / float(np.median(times32))}
+    del obj32, hvp32
+
     # (iii) CPU B3 on a bounded row sample (same D, same tolerance)
     import scipy.sparse.linalg as spla
     from oracle import glm
@@ -240,6 +267,7 @@ def hvp_cg_side_measurement(torch, device, n_rows, dim, cpu_rows, reps=10):
                                "row_iterations_per_s": nc * max(cpu_iters, 1) / cpu_s}}
     res_cg["speedup_row_iterations"] = res_cg["gpu_row_iterations_per_s"] / res_cg["cpu_baseline"]["row_iterations_per_s"]
     res_cg["block_cg"] = res_blk
+    res_cg["fp32_mode"] = res_f32
     return res_hvp, res_cg
 
 
@@ -631,6 +659,34 @@ def config4_leg(torch, dist, va, world, rank, device, group, coll_dev, rows_tota
                "hvp_with_all_reduce_ms": ms_apply,
                "row_iterations_per_s": N * max(iters, 1) / dt}
     del X, obj, hvp
+    torch.cuda.empty_cache()
+    # the optional fp32 STORAGE mode on the same rows: X kept in float (half the bytes per product), every sum fp64
+    X32, y32, _ = va.synth.glm_problem(n_local, dim, "logistic", seed=4, row0=rank * n_local, device=device,
+                                       dtype=torch.float32)
+    obj32 = va.WeightedGLMObjective(X32, y32, family="logistic", prior=1.0, process_group=group,
+                                    dtype=torch.float32)
+    hvp32 = cg.GLMHessianVectorProduct(obj32, theta, w)
+    _, r32, _ = vrows.glm_link(obj32, theta, w)
+    b32 = vrows.gemv_t2(obj32.X, r32, dw)
+    obj32._all_reduce(b32)
+    ms_local32 = timed(lambda: vrows.glm_hvp(obj32.X, hvp32.d, v, prior=None, out=out), 10)
+    cg.cg_solve(lambda p_, o_: hvp32.apply(p_, o_), b32, tol=tol, maxiter=3)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x32, info32, iters32 = cg.cg_solve(lambda p_, o_: hvp32.apply(p_, o_), b32, tol=tol)
+    torch.cuda.synchronize()
+    dt32 = _max_over_ranks(torch, dist, world, coll_dev, time.perf_counter() - t0)
+    if rank == 0:
+        res["fp32_mode"] = {
+            "note": "X stored in float (rows of 4 * D bytes), vectors and every sum fp64; optional mode, never the headline",
+            "cg_seconds": dt32, "cg_iterations": int(iters32), "cg_info": int(info32),
+            "hvp_local_kernel_ms": ms_local32,
+            "hvp_local_GBs": (4.0 * n_local * dim + 8.0 * n_local + 16.0 * dim) / (ms_local32 * 1e-3) / 1e9,
+            "solution_rel_diff_vs_fp64": float(((x32 - x).norm() / x.norm()).item()),
+            "speedup_vs_fp64": dt / dt32}
+    del X32, obj32, hvp32
     torch.cuda.empty_cache()
     return res
 

@@ -255,9 +255,11 @@ int    vt_glm_value(int family, const double* X_dev, int64_t ldx, const double* 
  * (its r, d, g are f32-accurate, ~1e-6: use vt_glm_grad_f32 / vt_glm_link_f32 where fp64 sums matter, e.g. an
  * optimiser's stopping test) and folds its f32 accumulators into fp64 every <= 4096 rows per wave.
  * D <= VT_SMALL_D_MAX for the f32-MFMA Hessian / TRSM kernels (beyond: the tiled route below, D <= 4096).  Row
- * operators: D <= 4096 when D and ldx are even and X is 8-byte aligned (two floats per lane), D <= 2048 otherwise
- * (odd D, odd ldx or a 4-byte aligned base take the scalar configurations); anything larger returns
- * VT_ERR_UNSUPPORTED (use the fp64 entry points).  Each entry point replaces the same
+ * operators: D <= 20448 when ldx is a multiple of 4 and X is 16-byte aligned (rows on a 16-byte pitch: four
+ * floats per lane above 4096 columns -- configs[3]'s D = 20000 CG route on a float X); else D <= 4096 when D and
+ * ldx are even and X is 8-byte aligned (two floats per lane), D <= 2048 otherwise (odd D, odd ldx or a 4-byte
+ * aligned base take the scalar configurations); anything larger returns VT_ERR_UNSUPPORTED (use the fp64 entry
+ * points, or pad the row pitch).  Each entry point replaces the same
  * reference lines as its fp64 namesake above and takes the same arguments, with float where noted. */
 size_t vt_glm_hessian_f32_workspace_bytes(int64_t N, int D);
 int    vt_glm_hessian_f32(int family, const float* X_dev, int64_t ldx, const double* theta_dev,
@@ -296,6 +298,8 @@ int    vt_glm_hvp_f32(const float* X_dev, int64_t ldx, const double* d_dev, cons
                       size_t ws_bytes, void* stream);
 int    vt_gemv_t_f32(const float* A_dev, int64_t lda, const double* u_dev, int64_t N, int D, double* out_dev,
                      void* ws_dev, size_t ws_bytes, void* stream);
+int    vt_gemv_t2_f32(const float* A_dev, int64_t lda, const double* u1_dev, const double* u2_dev, int64_t N, int D,
+                      double* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
 int    vt_gemv_f32(const float* A_dev, int64_t lda, const double* v_dev, int64_t N, int D, double* out_dev,
                    void* ws_dev, size_t ws_bytes, void* stream);
 int    vt_glm_value_f32(int family, const float* X_dev, int64_t ldx, const double* theta_dev,

@@ -216,9 +216,46 @@ def test_fp32_row_operators(relerr):
         u = np.sin(np.arange(N))
         assert relerr(rows.gemv_t(obj.X, torch.tensor(u, device="cuda")).cpu().numpy(), X32.T @ u) < 1e-11
         assert relerr(rows.gemv(obj.X, torch.tensor(v, device="cuda")).cpu().numpy(), X32 @ v) < EXACT
+        u2 = np.cos(0.3 * np.arange(N))
+        assert relerr(rows.gemv_t2(obj.X, torch.tensor(u, device="cuda"), torch.tensor(u2, device="cuda")).cpu().numpy(),
+                      X32.T @ (u * u2)) < 1e-11
         val = obj(theta, w)
         ref = glm.value(family, X32, y, theta, w, prior, 0.7, offset)
         assert abs(val - ref) <= 1e-11 * abs(ref)
+
+
+def test_fp32_cg_config4_d20000(relerr):
+    """BASELINE.json configs[3] (matrix-free CG, D = 20 000 ridge-logistic) on a FLOAT X: the wide row kernel on
+    16-byte lanes.  fp64 sums of float data: the device iteration tracks the oracle's CG on the rounded X step for
+    step, and lands within the mode's 1e-4 of the fp64 problem's solution."""
+    torch = _torch()
+    import vittles_amd as va
+    from vittles_amd.cg import GLMHessianVectorProduct
+    from vittles_amd import rows
+    from oracle import glm, solvers
+    N, D = 3000, 20000
+    X, y, w, _ = glm.synth(N, D, "logistic", seed=20)
+    X32 = X.astype(np.float32).astype(np.float64)
+    rng = np.random.default_rng(2)
+    theta = rng.standard_normal(D) / np.sqrt(D)
+    w = rng.uniform(0.5, 1.5, N)
+    dw = rng.standard_normal(N)
+    obj = va.WeightedGLMObjective(X, y, family="logistic", prior=1.0, dtype=torch.float32)
+    assert obj.X.dtype == torch.float32
+    hvp = GLMHessianVectorProduct(obj, theta, w)
+    _, r, _ = rows.glm_link(obj, torch.tensor(theta, device="cuda"), torch.tensor(w, device="cuda"))
+    b = rows.gemv_t2(obj.X, r, torch.tensor(dw, device="cuda")).cpu().numpy()       # jac0 @ dw
+    sols = {}
+    for name, Xr in (("rounded", X32), ("fp64", X)):
+        _, l1, l2 = glm.link("logistic", Xr @ theta, y)
+        mv = lambda u, Xr=Xr, dv=w * l2: Xr.T @ (dv * (Xr @ u)) + u
+        br = Xr.T @ (l1 * dw)              # d grad / d w_n = ell_n' x_n: no weight factor
+        sols[name] = (br, solvers.cg_legacy(mv, br, tol=1e-10, return_iters=True))
+    assert relerr(b, sols["rounded"][0]) < 1e-11
+    x = va.solver_lib.get_cg_solver(hvp, D, cg_opts={'tol': 1e-10})(b)
+    x_ref, info_ref, _ = sols["rounded"][1]
+    assert info_ref == 0 and relerr(x, x_ref) < 1e-8
+    assert relerr(x, sols["fp64"][1][0]) < MODE
 
 
 def test_fp32_newton_fit(relerr):

@@ -518,7 +518,7 @@ int launch_cfg(const RowArgs& a, const RowCfg& c, int grid, bool nt, hipStream_t
         // wide float rows (the fp32 mode at D > 4096): four floats per lane and chunk, OP by OP what the mode exposes
         if (c.team == kWideTeam && c.vec == 4) {
             if constexpr (OP == OP_LINK || OP == OP_GRAD || OP == OP_HVP || OP == OP_GEMV || OP == OP_GEMVT ||
-                          OP == OP_VALUE) {
+                          OP == OP_GEMVT2 || OP == OP_VALUE) {
                 if (c.cpt == 5) return launch_wide<OP, 4, 5, 5, float>(a, grid, st);
                 if (c.cpt == 10) return launch_wide<OP, 4, 10, (OP == OP_GRAD ? 6 : 10), float>(a, grid, st);
             }
@@ -764,7 +764,7 @@ extern "C" int vt_glm_hvp_noalloc(const double* X, int64_t ldx, const double* d,
 }
 
 // ---- fp32 storage mode (BASELINE.json north_star: "optional fp32 mode", 1e-4): X (or any streamed matrix) is
-// float, D <= 4096; vectors, per-row outputs and every accumulation stay fp64.  Same kernels, XT = float.
+// float (D <= 4096, or <= 20448 with rows on a 16-byte pitch); vectors, per-row outputs and every accumulation stay fp64.  Same kernels, XT = float.
 extern "C" int vt_glm_link_f32(int family, const float* X, int64_t ldx, const double* theta, const double* y,
                                const double* w, const double* offset, double scale, int64_t N, int D,
                                double* z_out, double* r_out, double* d_out, void* ws, size_t ws_bytes,
@@ -815,6 +815,19 @@ extern "C" int vt_gemv_t_f32(const float* X, int64_t ldx, const double* u, int64
     if (N > 0) {
         RowArgs a{X, ldx, N, D, nullptr, nullptr, nullptr, nullptr, u, 1.0, 0, nullptr, nullptr, nullptr, (double*)ws};
         P = run_rows<OP_GEMVT, float>(a, st);
+        if (P < 0) return P;
+    }
+    return finalize((const double*)ws, D, P, D, 0, 1.0, nullptr, nullptr, 0.0, out, st);
+}
+
+extern "C" int vt_gemv_t2_f32(const float* X, int64_t ldx, const double* u1, const double* u2, int64_t N, int D,
+                              double* out, void* ws, size_t ws_bytes, void* stream) {
+    VT_ROWS_PROLOGUE
+    if (!out || (N > 0 && (!u1 || !u2))) return VT_ERR_BAD_ARG;
+    int P = 0;
+    if (N > 0) {
+        RowArgs a{X, ldx, N, D, nullptr, u2, nullptr, nullptr, u1, 1.0, 0, nullptr, nullptr, nullptr, (double*)ws};
+        P = run_rows<OP_GEMVT2, float>(a, st);
         if (P < 0) return P;
     }
     return finalize((const double*)ws, D, P, D, 0, 1.0, nullptr, nullptr, 0.0, out, st);

@@ -89,9 +89,11 @@ class WeightedGLMObjective(RegisteredObjective):
 
     ``dtype=torch.float32`` selects the fp32 STORAGE mode (BASELINE.json north_star: optional, 1e-4
     against the fp64 oracle, never the headline): X is kept -- and the sensitivity matrix returned -- in
-    float, half the HBM bytes; theta, y, w, r, d, H, g and the Cholesky factor stay double.  D <= 4096 for even D
-    (the row operators' limit; odd D: 2048): up to 128 the f32-MFMA resident kernels, beyond the tiled kernels on float panels with fp64
-    products and a slab-wise fp64 solve (configs[2]'s D = 1000 with X and S at half the footprint)."""
+    float, half the HBM bytes; theta, y, w, r, d, H, g and the Cholesky factor stay double.  Hessian route: D <= 4096 --
+    up to 128 the f32-MFMA resident kernels, beyond the tiled kernels on float panels with fp64 products and a
+    slab-wise fp64 solve (configs[2]'s D = 1000 with X and S at half the footprint).  Row operators (link, gradient,
+    value, HVP and the CG route, A v, A^T u): D <= 20448, rows are re-laid on a 16-byte pitch here (configs[3]'s
+    D = 20000 on a float X)."""
 
     def __init__(self, X, y, family="logistic", prior=None, scale=1.0, offset=None,
                  device=None, process_group=None, dtype=torch.float64):
@@ -159,7 +161,7 @@ class WeightedGLMObjective(RegisteredObjective):
             self.N, self.D)
         if nbytes == 0:
             raise _lib.VittlesHipError("vt_glm_hessian%s does not support D = %d"
-                                       % ("_f32 (fp32 mode: D <= 4096)" if f32 else "", self.D))
+                                       % ("_f32 (fp32 mode: D <= 4096 for the Hessian route; the CG route takes D <= 20448)" if f32 else "", self.D))
         # scratch per stream: two streams driving one objective never share it
         skey = dev.stream_ptr()
         if self._ws is None:

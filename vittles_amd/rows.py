@@ -84,13 +84,13 @@ def gemv(A, v):
 def gemv_t2(A, u1, u2):
     """out (D,) = A^T (u1 .* u2) for a row-major (N, D) CUDA tensor A."""
     lib = dev.require_gpu()
-    _fp64_only(A, "gemv_t2")
     A = _rowmajor(A)
     N, D = A.shape
     out = torch.empty(D, dtype=torch.float64, device=A.device)
     ws = _workspace(D, A.device)
-    _lib.check(lib.vt_gemv_t2(A.data_ptr(), dev.ld(A), u1.contiguous().data_ptr(), u2.contiguous().data_ptr(),
-                              N, D, out.data_ptr(), ws.data_ptr(), ws.numel() * 8, dev.stream_ptr()), "vt_gemv_t2")
+    _lib.check(_lib.fn(lib, "vt_gemv_t2", A)(A.data_ptr(), dev.ld(A), u1.contiguous().data_ptr(),
+                                             u2.contiguous().data_ptr(), N, D, out.data_ptr(), ws.data_ptr(),
+                                             ws.numel() * 8, dev.stream_ptr()), "vt_gemv_t2")
     return out
 
 
