@@ -214,6 +214,20 @@ int    vt_glm_taylor2_rhs(int family, const double* X_dev, int64_t ldx, const do
                           const double* dw_dev, double scale, const double* u_dev, int64_t N, int D,
                           double* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* ANY order k of the data-weight Taylor expansion (2 <= k <= VT_TAYLOR_MAX_ORDER), as a per-row coefficient:
+ *   c_n = scale * [ w_n  sum_{m=2..min(k, mio)}    ell^(m+1)(z_n) B_{k,m}(zeta_1, ..)
+ *                 + k dw_n sum_{m=1..min(k-1, mio)} ell^(m+1)(z_n) B_{k-1,m}(zeta_1, ..) ]
+ * with zeta_dev a (k-1) x N array (row j-1, leading dimension ldz: zeta_j = X d_j from vt_gemv), B_{n,m} the
+ * partial Bell polynomials and mio = max_input_order (>= k: no truncation; the reference drops every term with
+ * more input partial derivatives than that, :1247-1249).  The order-k derivative of the optimum is
+ * -H^{-1} X^T c (vt_gemv_t + the Cholesky solve); orders 2 and 3 also have the one-pass kernels around this.
+ * Replaces: ParametricSensitivityTaylorExpansion._evaluate_dkinput_dhyperk vittles/sensitivity_lib.py:1209-1260 at
+ *           any order (the reference's nested autograd.make_jvp terms, :495-688, for the registered GLM objective). */
+#define VT_TAYLOR_MAX_ORDER 8
+int    vt_glm_taylor_coeff(int family, const double* z_dev, const double* w_dev, const double* dw_dev,
+                           const double* zeta_dev, int64_t ldz, double scale, int order, int max_input_order,
+                           int64_t N, double* c_dev, void* stream);
+
 /* Third-order data-weight term of a GLM, one pass over X (zeta2_dev = X d2 from vt_gemv, u1 = d1):
  *   out = scale * sum_n [ w_n (ell'''' z1^3 + 3 ell''' z1 z2) + 3 dw_n (ell''' z1^2 + ell'' z2) ] x_n,
  *   z1 = x_n.d1, z2 = zeta2_n; the third directional derivative of the optimum is -H^{-1} out.

@@ -1,5 +1,5 @@
-"""ORACLE (test infrastructure, never a product path): the first two directional derivatives
-of the optimum in the data weights, restating what
+"""ORACLE (test infrastructure, never a product path): the directional derivatives
+of the optimum in the data weights (closed forms for orders 1-3, power-series composition for any order), restating what
 ``ParametricSensitivityTaylorExpansion`` (``/root/reference/vittles/sensitivity_lib.py:1021-1363``)
 evaluates for the registered weighted-GLM objective.
 
@@ -44,6 +44,78 @@ def link4(family, z):
     return np.zeros_like(z)
 
 
+def _stirling2(n, k):
+    """Stirling numbers of the second kind (exact integers)."""
+    if n == k:
+        return 1
+    if k == 0 or k > n:
+        return 0
+    return k * _stirling2(n - 1, k) + _stirling2(n - 1, k - 1)
+
+
+def link_derivs(family, z, kmax):
+    """{m: d^m ell / dz^m} for m = 2..kmax.  Logistic: ell' = sigma(z) - y and the closed form
+    sigma^(n) = sum_{j=1..n+1} (-1)^(j-1) (j-1)! S(n+1, j) sigma^j  (S: Stirling numbers of the second kind)."""
+    from math import factorial
+    out = {}
+    if family == "logistic":
+        p = glm._sigmoid(z)
+        for m in range(2, kmax + 1):
+            n = m - 1
+            out[m] = sum((-1.0) ** (j - 1) * factorial(j - 1) * _stirling2(n + 1, j) * p ** j for j in range(1, n + 2))
+    elif family == "poisson":
+        ez = np.exp(z)
+        for m in range(2, kmax + 1):
+            out[m] = ez
+    elif family == "gaussian":
+        for m in range(2, kmax + 1):
+            out[m] = np.ones_like(z) if m == 2 else np.zeros_like(z)
+    else:
+        raise ValueError(family)
+    return out
+
+
+def rhs_coeff(family, z, w, dw, zetas, k, max_input_order=None, scale=1.0):
+    """Per-row coefficient c of the order-k equation  H d_k = -X^T c  by POWER-SERIES composition: with
+    delta(eps) = sum_{j<k} zeta_j eps^j / j!  (zeta_j = X d_j; the unknown zeta_k is left out -- it is the H d_k term),
+    c = scale * k! * [eps^k] (w + eps dw) * sum_{m=1..mio} ell^(m+1)(z) delta(eps)^m / m!.
+    The m-th power of delta carries m input partial derivatives of the estimating equation, which is what the
+    reference's ``max_input_order`` truncates (:1247-1249)."""
+    from math import factorial
+    N = len(z)
+    mio = k if max_input_order is None else min(int(max_input_order), k)
+    ld = link_derivs(family, z, k + 1)
+    delta = np.zeros((N, k + 1))
+    for j, zj in enumerate(zetas[:k - 1], start=1):
+        delta[:, j] = zj / factorial(j)
+    comp = np.zeros((N, k + 1))
+    pw = np.zeros((N, k + 1))
+    pw[:, 0] = 1.0
+    for m in range(1, mio + 1):
+        nxt = np.zeros_like(pw)
+        for a in range(k + 1):              # truncated product pw * delta
+            for b in range(1, k + 1 - a):
+                nxt[:, a + b] += pw[:, a] * delta[:, b]
+        pw = nxt
+        comp += (ld[m + 1] / factorial(m))[:, None] * pw
+    total = w[:, None] * comp
+    total[:, 1:] += dw[:, None] * comp[:, :-1]
+    return scale * factorial(k) * total[:, k]
+
+
+def input_derivs_general(family, X, y, theta, w, dw, prior=None, scale=1.0, offset=None, max_order=4,
+                         max_input_order=None):
+    """``input_derivs`` for ANY order through ``rhs_coeff`` (orders 1..3 agree with the closed forms below)."""
+    z = glm.linear_predictor(X, theta, offset)
+    _, l1, _ = glm.link(family, z, y)
+    chol = scipy.linalg.cho_factor(glm.hessian(family, X, y, theta, w, prior, scale, offset))
+    out = [-scipy.linalg.cho_solve(chol, X.T @ (scale * l1 * dw))]
+    for k in range(2, max_order + 1):
+        c = rhs_coeff(family, z, w, dw, [X @ d for d in out], k, max_input_order, scale)
+        out.append(-scipy.linalg.cho_solve(chol, X.T @ c))
+    return out
+
+
 def input_derivs(family, X, y, theta, w, dw, prior=None, scale=1.0, offset=None, max_order=2,
                  max_input_order=None):
     """[d theta/dw . dw,  d^2 theta/dw^2 [dw, dw], ...] at (theta, w) (reference: evaluate_input_derivs,
@@ -51,8 +123,10 @@ def input_derivs(family, X, y, theta, w, dw, prior=None, scale=1.0, offset=None,
     partial derivatives w.r.t. the input (``total_eta_order``) exceeds it (:1247-1249); a term
     ``w l_{m+1} (...) x`` is an m-th input partial of G, a term ``dw l_{m+1} (...) x`` an m-th input and
     first hyper partial (l_k = k-th link derivative)."""
-    if max_order < 1 or (max_order > 3 and family != "gaussian"):
-        raise ValueError("oracle covers orders 1 to 3 (any order for the gaussian family)")
+    if max_order < 1:
+        raise ValueError("max_order must be at least one")
+    if max_order > 3 and family != "gaussian":
+        return input_derivs_general(family, X, y, theta, w, dw, prior, scale, offset, max_order, max_input_order)
     z = glm.linear_predictor(X, theta, offset)
     _, l1, _ = glm.link(family, z, y)
     l2, l3 = link3(family, z)

@@ -94,11 +94,12 @@ def glm_checks(rank, world, group, family, N, D):
     H_full = glm.hessian(family, X, y, theta_ref, w, prior)
     assert Xk.shape == (D, 6) and rel(Xk, np.linalg.solve(H_full, Bk)) < 1e-8, rel(Xk, np.linalg.solve(H_full, Bk))
 
-    # second-order data-weight terms: partial right-hand sides all-reduced
-    te = va.ParametricSensitivityTaylorExpansion.optimization_objective(obj, theta_ref, w[a:b], order=2)
+    # data-weight Taylor terms up to order 4 (fused kernels to order 3, the Faa di Bruno route above): partial
+    # right-hand sides all-reduced
+    te = va.ParametricSensitivityTaylorExpansion.optimization_objective(obj, theta_ref, w[a:b], order=4)
     ds = te.evaluate_input_derivs((w_new - w)[a:b])
-    ds_ref = taylor.input_derivs(family, X, y, theta_ref, w, w_new - w, prior=prior, max_order=2)
-    for k in range(2):
+    ds_ref = taylor.input_derivs(family, X, y, theta_ref, w, w_new - w, prior=prior, max_order=4)
+    for k in range(4):
         assert rel(ds[k], ds_ref[k]) < 1e-9, ("taylor", k, rel(ds[k], ds_ref[k]))
     # fp32 storage mode on the same shards (row n1): float X and S, all-reduced fp64 H, 1e-4
     if D <= 128:

@@ -363,3 +363,34 @@ def test_taylor_oracle_vs_torch_ad_of_the_estimating_equation(family):
         e3 = 5e-2
         fd3 = (opt(w + 2 * e3 * dw) - 2 * opt(w + e3 * dw) + 2 * opt(w - e3 * dw) - opt(w - 2 * e3 * dw)) / (2 * e3 ** 3)
         assert rel(d3, fd3) < 5e-3
+
+
+@pytest.mark.parametrize("family", ["logistic", "poisson"])
+def test_taylor_oracle_any_order_against_refits(family):
+    """oracle.taylor.input_derivs_general (power-series composition) is pinned two ways: it reproduces the closed
+    forms of orders 1-3 (also under max_input_order), and the order-K series misses a RE-FITTED optimum by
+    O(eps^(K+1)) -- halving eps divides the error by 2^(K+1) for K = 3..6."""
+    from math import factorial
+    from oracle import glm, taylor
+    N, D = 400, 5
+    X, y, w, _ = glm.synth(N, D, family, seed=3)
+    if family == "poisson":
+        X = 0.3 * X
+    rng = np.random.default_rng(0)
+    w = rng.uniform(0.5, 1.5, N)
+    dw = 0.5 * rng.standard_normal(N)
+    theta = glm.newton_optimum(family, X, y, w, prior=1.0)
+    gen = taylor.input_derivs_general(family, X, y, theta, w, dw, prior=1.0, max_order=6)
+    for mio in (None, 1, 2):
+        closed = taylor.input_derivs(family, X, y, theta, w, dw, prior=1.0, max_order=3, max_input_order=mio)
+        g = gen if mio is None else taylor.input_derivs_general(family, X, y, theta, w, dw, prior=1.0, max_order=3,
+                                                                 max_input_order=mio)
+        for k in range(3):
+            assert np.abs(closed[k] - g[k]).max() <= 1e-13 * np.abs(closed[k]).max()
+    for K in (3, 4, 5, 6):
+        errs = []
+        for eps in (0.2, 0.1):
+            refit = glm.newton_optimum(family, X, y, w + eps * dw, prior=1.0)
+            series = theta + sum(gen[j] * eps ** (j + 1) / factorial(j + 1) for j in range(K))
+            errs.append(np.abs(series - refit).max())
+        assert 0.8 * 2 ** (K + 1) < errs[0] / errs[1] < 1.25 * 2 ** (K + 1), (K, errs)

@@ -1,31 +1,24 @@
-"""Dev tool: parity of the fused Hessian pass vs the oracle for a list of D (N large enough for the tile kernel).
-python tools/check_hess.py 100 97 104 112"""
+"""Dev check of one Hessian build against plain fp64 torch (usage: VITTLES_HIP_LIB=... python tools/check_hess.py D [N])"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 import vittles_amd as va
-from oracle import glm
-
-Ds = [int(a) for a in sys.argv[1:]] or [100]
-worst = 0.0
-for D in Ds:
-    for fam, N, off in (("logistic", 20011, False), ("poisson", 4100, True), ("gaussian", 9999, False)):
-        X, y, w, _ = glm.synth(N, D, fam, seed=D + N)
-        rng = np.random.default_rng(D)
-        w = rng.uniform(0.2, 1.8, N)
-        theta = rng.standard_normal(D) / np.sqrt(D) * (0.3 if fam == "poisson" else 1.0)
-        offset = rng.standard_normal(N) * 0.1 if off else None
-        obj = va.WeightedGLMObjective(X, y, family=fam, prior=0.7, scale=1.3, offset=offset)
-        out = obj.fused(theta, w)
-        H = glm.hessian(fam, X, y, theta, w, 0.7, 1.3, offset)
-        g = glm.grad(fam, X, y, theta, w, 0.7, 1.3, offset)
-        _, l1, l2 = glm.link(fam, glm.linear_predictor(X, theta, offset), y)
-        errs = [np.abs(out["H"].cpu().numpy() - H).max() / np.abs(H).max(),
-                np.abs(out["g"].cpu().numpy() - g).max() / np.abs(g).max(),
-                np.abs(out["r"].cpu().numpy() - 1.3 * l1).max() / np.abs(l1).max(),
-                np.abs(out["d"].cpu().numpy() - 1.3 * w * l2).max() / np.abs(w * l2).max()]
-        worst = max(worst, max(errs))
-        print("D=%d %s N=%d: H %.1e g %.1e r %.1e d %.1e" % (D, fam, N, *errs), flush=True)
-print("worst", worst, "OK" if worst < 1e-10 else "FAIL")
-sys.exit(0 if worst < 1e-10 else 1)
+D = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 100003
+torch.manual_seed(D)
+X = torch.randn((N, D), dtype=torch.float64, device="cuda")
+y = (torch.rand(N, dtype=torch.float64, device="cuda") < 0.5).double()
+w = torch.rand(N, dtype=torch.float64, device="cuda") + 0.5
+theta = torch.randn(D, dtype=torch.float64, device="cuda") / D ** 0.5
+obj = va.WeightedGLMObjective(X, y, family="logistic", prior=1.0)
+f = obj.fused(theta, w)
+z = X @ theta
+p = torch.sigmoid(z)
+d = w * p * (1 - p)
+H = X.t() @ (d[:, None] * X) + torch.eye(D, dtype=torch.float64, device="cuda")
+g = X.t() @ (w * (p - y)) + theta
+eh = float((f["H"] - H).abs().max() / H.abs().max())
+eg = float((f["g"] - g).abs().max() / g.abs().max())
+ed = float((f["d"] - d).abs().max())
+print(os.environ.get("VITTLES_HIP_LIB", "default")[-14:], "D=%d N=%d H %.1e g %.1e d %.1e" % (D, N, eh, eg, ed), "OK" if max(eh, eg, ed) < 1e-12 else "FAIL")
+sys.exit(0 if max(eh, eg, ed) < 1e-12 else 1)

@@ -105,6 +105,7 @@ SIGNATURES = {
     "vt_glm_hvp_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_dbl, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size_t,
                                c_ptr]),
     "vt_gemv_t_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size_t, c_ptr]),
+    "vt_glm_taylor_coeff": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_dbl, c_int, c_int, c_i64, c_ptr, c_ptr]),
     "vt_gemv_t2_f32": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size_t, c_ptr]),
     "vt_gemv_f32": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size_t, c_ptr]),
     "vt_glm_value_f32": (c_int, [c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_dbl, c_i64, c_int,

@@ -430,7 +430,7 @@ struct TileRows {
 
 // SERVICE wave (wave group 0, one per SIMD): links the RPS rows [RPS*simd, RPS*(simd+1)) of tile p+1 in period p.
 // The tile landed a period ago: MFMA wave 0 of this SIMD issued its DMA and waited for it before the barrier.
-template <int NB, int FAM>
+template <int NB, int FAM, int TURNS>
 __device__ __forceinline__ void hess_tile_service(const HessArgs& a, double* lds, int64_t mine, int simd) {
     using LY = TileLds<NB>;
     constexpr int RS = LY::RS, TR = LY::TR;
@@ -515,16 +515,23 @@ __device__ __forceinline__ void hess_tile_service(const HessArgs& a, double* lds
         if (q == 0) gl[simd * (NB * 16) + 16 * b + c] = v;
     }
 #pragma unroll
-    for (int turn = 0; turn < kTileNM; ++turn) vt_lds_barrier();   // the MFMA waves' reduction turns
+    for (int turn = 0; turn < TURNS; ++turn) vt_lds_barrier();   // the MFMA waves' reduction turns
 }
 
-// MFMA wave ks (wave group ks + 1) of quarter Q (= SIMD): k-steps [kbeg, kbeg + kcnt) of every tile, for the
-// blocks the quarter owns.  Wave 0 also feeds the pipeline: DMA of tile p+2 at the start of period p.
-template <int NB, int NS, int Q>
-__device__ __forceinline__ void hess_tile_mfma(const HessArgs& a, double* lds, int64_t mine, int ks) {
+// MFMA wave ks (wave group ks + 1) of a SIMD.  Two ways to deal out a tile's products:
+//   KSP = false: the SIMD owns a QUARTER Q of the block triangle and its MFMA waves split the tile's k-steps;
+//   KSP = true : the SIMD owns a quarter of the tile's K-STEPS (the very rows its service wave links and its wave 0
+//                fetches) for the WHOLE triangle, which its MFMA waves split between them (Q = ks: a cost-balanced
+//                part, column-wise).  Every SIMD's pipe then carries exactly the same work (the 64-cycle
+//                granularity of whole blocks leaves the quarters of D = 100 at 384 / 368 / 352 / 352 cycles per
+//                k-step), and a wave reads 7-9 operands for 13-15 products instead of 8 for 7.
+// Wave 0 also feeds the pipeline: DMA of tile p+2 at the start of period p.
+template <int NB, int NS, int Q, bool KSP>
+__device__ __forceinline__ void hess_tile_mfma(const HessArgs& a, double* lds, int64_t mine, int ks, int simd_rt) {
     using LY = TileLds<NB>;
-    constexpr int NQ = kTileNQ, RS = LY::RS, TR = LY::TR;
+    constexpr int NQ = KSP ? kTileNM : kTileNQ, RS = LY::RS, TR = LY::TR;
     constexpr OwnTab TAB = make_own(NB, NS, NQ);
+    const int simd = KSP ? simd_rt : Q;                // the SIMD this wave runs on (whose rows its wave 0 fetches)
     constexpr bool STRIP = strip_needed(TAB, NB, NS, Q);
     // ownership as compile-time bit masks (bit blk_ord(i, j) / bit b / bit j): the unrolled loops below test
     // plain constants -- left to fold make_own()'s loops per iteration, the optimiser sometimes does not
@@ -538,14 +545,15 @@ __device__ __forceinline__ void hess_tile_mfma(const HessArgs& a, double* lds, i
 #define VT_TILE_K0_DELTA 0   // dev switch: k-steps taken from the DMA-issuing wave and given to the other one(s)
 #endif
     constexpr int K0 = KSTEPS / kTileNM - VT_TILE_K0_DELTA;   // wave 0 (which also issues the DMA): 6 of 12, 4 of 9
-    static_assert((KSTEPS - K0) % (kTileNM - 1) == 0, "k-step split");
+    static_assert(KSP || (KSTEPS - K0) % (kTileNM - 1) == 0, "k-step split");
+    static_assert(!KSP || KSTEPS % kTileNQ == 0, "k-steps per SIMD");
     constexpr int KR = (KSTEPS - K0) / (kTileNM - 1);
     constexpr int RPS = TR / 4;
     constexpr int CH = RS / 2;                         // 16-byte chunks per LDS row
     constexpr int DMAH = (CH + 63) / 64;               // DMA instructions per row
     static_assert(2 * RPS <= 64, "one DMA instruction moves a SIMD's per-row scalars");
-    const int kbeg = ks == 0 ? 0 : K0 + (ks - 1) * KR;
-    const int kcnt = ks == 0 ? K0 : KR;
+    const int kbeg = KSP ? simd * (KSTEPS / kTileNQ) : (ks == 0 ? 0 : K0 + (ks - 1) * KR);
+    const int kcnt = KSP ? KSTEPS / kTileNQ : (ks == 0 ? K0 : KR);
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, c = lane & 15;
     const TileRows<TR> tiles{a, mine};
@@ -556,10 +564,10 @@ __device__ __forceinline__ void hess_tile_mfma(const HessArgs& a, double* lds, i
     auto dma = [&](int64_t k, int buf) {
         const int nrow = (VT_ABL & 2) ? 0 : tiles.nrow(k);
         const int64_t rb = nrow > 0 ? tiles.first_row(k) : 0;
-        const double* xb = a.X + (rb + RPS * Q) * a.ldx;
+        const double* xb = a.X + (rb + RPS * simd) * a.ldx;
 #pragma unroll
         for (int rr = 0; rr < RPS; ++rr) {
-            const int row = RPS * Q + rr;
+            const int row = RPS * simd + rr;
             __amdgpu_buffer_rsrc_t xrs = tile_rsrc(xb + (int64_t)rr * a.ldx, row < nrow ? 8u * a.D : 0u);
             double* dst = lds + LY::kTile + buf * (TR * RS) + row * RS;
 #pragma unroll
@@ -570,8 +578,8 @@ __device__ __forceinline__ void hess_tile_mfma(const HessArgs& a, double* lds, i
             }
         }
         if (lane < 2 * RPS) {
-            const unsigned vo = 8u * (RPS * Q) + 4u * lane;
-            const int so = buf * TR + RPS * Q;
+            const unsigned vo = 8u * (RPS * simd) + 4u * lane;
+            const int so = buf * TR + RPS * simd;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(tile_rsrc(a.y + rb, 8u * nrow), (vt_ldsptr)(lds + LY::kY + so), 4, vo, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(tile_rsrc(a.w + rb, 8u * nrow), (vt_ldsptr)(lds + LY::kW + so), 4, vo, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(tile_rsrc(a.offset + rb, a.offset ? 8u * nrow : 0u),
@@ -657,11 +665,13 @@ __device__ __forceinline__ void hess_tile_mfma(const HessArgs& a, double* lds, i
         b0 = b0 == 2 ? 0 : b0 + 1;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every tile is dead
-    // H: the MFMA waves of a quarter add up in LDS in the order ks = 0, 1, ...
+    // H: the waves that hold parts of the same blocks add up in LDS in a fixed order: the MFMA waves of a quarter
+    // (ks = 0, 1, ...), or the SIMDs (0..3) when each of them holds the whole triangle
     double* hl = lds;                  // [NBT*256]
+    constexpr int TURNS = KSP ? kTileNQ : kTileNM;
 #pragma unroll
-    for (int turn = 0; turn < kTileNM; ++turn) {
-        if (ks == turn) {
+    for (int turn = 0; turn < TURNS; ++turn) {
+        if ((KSP ? simd : ks) == turn) {
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -681,6 +691,12 @@ __device__ __forceinline__ void hess_tile_mfma(const HessArgs& a, double* lds, i
     }
 }
 
+#ifndef VT_TILE_KSPLIT
+#define VT_TILE_KSPLIT 1   // dev switch: 0 = quarters of the block triangle per SIMD for every NB
+#endif
+// k-steps per SIMD need 4 | TR / 4 (48-row tiles: NB <= 7) and half the triangle's accumulators in one wave
+__host__ __device__ constexpr bool tile_ksplit(int NB) { return VT_TILE_KSPLIT && (tile_rows(NB) / 4) % kTileNQ == 0 && NB <= 7; }
+
 template <int NB, int NS, int FAM>
 __global__ __launch_bounds__(kTileThreads) void k_glm_hess_tile(HessArgs a) {
     using LY = TileLds<NB>;
@@ -694,14 +710,19 @@ __global__ __launch_bounds__(kTileThreads) void k_glm_hess_tile(HessArgs a) {
     const int64_t mine = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int simd = wid & 3, grp = wid >> 2;
+    constexpr bool KSP = tile_ksplit(NB);
     if (grp == 0) {
-        hess_tile_service<NB, FAM>(a, lds, mine, simd);
+        hess_tile_service<NB, FAM, KSP ? kTileNQ : kTileNM>(a, lds, mine, simd);
+    } else if constexpr (KSP) {
+        static_assert(!KSP || kTileNM == 2, "two MFMA waves per SIMD split the triangle");
+        if (grp == 1) hess_tile_mfma<NB, NS, 0, true>(a, lds, mine, 0, simd);    // part = MFMA wave
+        else hess_tile_mfma<NB, NS, 1, true>(a, lds, mine, 1, simd);
     } else {
         switch (simd) {   // quarter = SIMD
-            case 0: hess_tile_mfma<NB, NS, 0>(a, lds, mine, grp - 1); break;
-            case 1: hess_tile_mfma<NB, NS, 1>(a, lds, mine, grp - 1); break;
-            case 2: hess_tile_mfma<NB, NS, 2>(a, lds, mine, grp - 1); break;
-            default: hess_tile_mfma<NB, NS, 3>(a, lds, mine, grp - 1); break;
+            case 0: hess_tile_mfma<NB, NS, 0, false>(a, lds, mine, grp - 1, 0); break;
+            case 1: hess_tile_mfma<NB, NS, 1, false>(a, lds, mine, grp - 1, 1); break;
+            case 2: hess_tile_mfma<NB, NS, 2, false>(a, lds, mine, grp - 1, 2); break;
+            default: hess_tile_mfma<NB, NS, 3, false>(a, lds, mine, grp - 1, 3); break;
         }
     }
     double* out = a.part + (int64_t)blockIdx.x * L;

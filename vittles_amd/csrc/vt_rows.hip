@@ -856,3 +856,87 @@ extern "C" int vt_glm_value_f32(int family, const float* X, int64_t ldx, const d
     }
     return finalize((const double*)ws, D, P, 1, D, scale, nullptr, nullptr, 0.0, value_out, st);
 }
+
+// ---- data-weight Taylor expansion, ANY order (orders 2 and 3 have the fused one-pass kernels above) ---------------
+// Order k of the expansion of theta(w + eps dw):  H d_k = -X^T c,
+//   c_n = scale * [ w_n  sum_{m=2..min(k, mio)}   ell^(m+1)(z_n) B_{k,m}(zeta_1..)
+//                 + k dw_n sum_{m=1..min(k-1, mio)} ell^(m+1)(z_n) B_{k-1,m}(zeta_1..) ],   zeta_j = x_n . d_j,
+// B_{n,m} the partial Bell polynomials (Faa di Bruno for ell'(z(eps)); the m = 1 term of the first sum is H d_k
+// itself).  A term with ell^(m+1) is an m-th input partial derivative of the estimating equation, which is what
+// max_input_order (mio) cuts.  Per row: the link derivatives (logistic: polynomials in sigma from the compile-time
+// table P_{m+1} = P_m' (s - s^2); Poisson: e^z; Gaussian: ell'' = 1) and the Bell triangle by its recurrence
+// B_{n,m} = sum_i C(n-1, i-1) zeta_i B_{n-i,m-1}.  An N-vector pass: the two passes over X are vt_gemv / vt_gemv_t.
+namespace {
+constexpr int kTaylorMax = VT_TAYLOR_MAX_ORDER;
+struct TaylorTabs {
+    double lg[kTaylorMax + 2][kTaylorMax + 3];   // lg[m][i]: coefficient of sigma^i in d^m/dz^m log(1 + e^z), m >= 1
+    double binom[kTaylorMax + 1][kTaylorMax + 1];
+};
+constexpr TaylorTabs make_taylor_tabs() {
+    TaylorTabs t{};
+    t.lg[1][1] = 1.0;
+    for (int m = 1; m <= kTaylorMax; ++m)
+        for (int i = 1; i <= m; ++i) {
+            t.lg[m + 1][i] += i * t.lg[m][i];
+            t.lg[m + 1][i + 1] -= i * t.lg[m][i];
+        }
+    for (int n = 0; n <= kTaylorMax; ++n) {
+        t.binom[n][0] = 1.0;
+        for (int r = 1; r <= n; ++r) t.binom[n][r] = t.binom[n - 1][r - 1] + (r <= n - 1 ? t.binom[n - 1][r] : 0.0);
+    }
+    return t;
+}
+__constant__ TaylorTabs c_taylor = make_taylor_tabs();
+
+__global__ __launch_bounds__(256) void k_glm_taylor_coeff(int family, const double* z, const double* w, const double* dw,
+                                                          const double* zeta, int64_t ldz, double scale, int k, int mio,
+                                                          int64_t N, double* c) {
+    for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        double ld[kTaylorMax + 2];               // ld[m] = ell^(m)(z_n), m = 2..k+1
+        const double zn = z[n];
+        if (family == VT_FAMILY_LOGISTIC) {
+            const double e = exp(-fabs(zn));
+            const double sg = zn >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+            for (int m = 2; m <= k + 1; ++m) {
+                double p = 0.0;
+                for (int i = m; i >= 1; --i) p = fma(p, sg, c_taylor.lg[m][i]);
+                ld[m] = p * sg;
+            }
+        } else if (family == VT_FAMILY_POISSON) {
+            const double ez = exp(zn);
+            for (int m = 2; m <= k + 1; ++m) ld[m] = ez;
+        } else {
+            for (int m = 2; m <= k + 1; ++m) ld[m] = m == 2 ? 1.0 : 0.0;
+        }
+        double x[kTaylorMax + 1];
+        for (int j = 1; j <= k; ++j) x[j] = j < k ? zeta[(int64_t)(j - 1) * ldz + n] : 0.0;
+        double B[kTaylorMax + 1][kTaylorMax + 1];
+        for (int a = 0; a <= k; ++a)
+            for (int m = 0; m <= k; ++m) B[a][m] = 0.0;
+        B[0][0] = 1.0;
+        for (int a = 1; a <= k; ++a)
+            for (int m = 1; m <= a; ++m) {
+                double sacc = 0.0;
+                for (int i = 1; i <= a - m + 1; ++i) sacc = fma(c_taylor.binom[a - 1][i - 1] * x[i], B[a - i][m - 1], sacc);
+                B[a][m] = sacc;
+            }
+        double s1 = 0.0, s2 = 0.0;
+        for (int m = 2; m <= k && m <= mio; ++m) s1 = fma(ld[m + 1], B[k][m], s1);
+        for (int m = 1; m <= k - 1 && m <= mio; ++m) s2 = fma(ld[m + 1], B[k - 1][m], s2);
+        c[n] = scale * (w[n] * s1 + (double)k * dw[n] * s2);
+    }
+}
+}  // namespace
+
+extern "C" int vt_glm_taylor_coeff(int family, const double* z, const double* w, const double* dw, const double* zeta,
+                                   int64_t ldz, double scale, int order, int max_input_order, int64_t N, double* c,
+                                   void* stream) {
+    if (N < 0 || family < 0 || family > 2) return VT_ERR_BAD_ARG;
+    if (order < 2 || order > kTaylorMax) return VT_ERR_UNSUPPORTED;
+    if (N == 0) return VT_OK;
+    if (!z || !w || !dw || !zeta || !c || ldz < N || max_input_order < 1) return VT_ERR_BAD_ARG;
+    const int grid = (int)std::min<int64_t>((N + 255) / 256, (int64_t)num_cu() * 8);
+    hipLaunchKernelGGL(k_glm_taylor_coeff, dim3(grid), dim3(256), 0, (hipStream_t)stream, family, z, w, dw, zeta, ldz,
+                       scale, order, max_input_order, N, c);
+    return vt_launch_status();
+}

@@ -124,6 +124,35 @@ def glm_taylor3_rhs(obj, z, w, dw, d1, d2=None, zeta2=None):
     return out
 
 
+TAYLOR_MAX_ORDER = 8      # VT_TAYLOR_MAX_ORDER of include/vittles_hip.h
+
+
+def glm_taylor_rhs(obj, z, w, dw, derivs, k, max_input_order=None, zetas=None):
+    """Order-``k`` data-weight right-hand side of a WeightedGLMObjective for ANY 2 <= k <= TAYLOR_MAX_ORDER:
+    ``X^T c`` with the per-row Faa di Bruno coefficient ``c`` of ``vt_glm_taylor_coeff`` (partial Bell polynomials of
+    ``zeta_j = X d_j``, j < k).  ``derivs``: the k - 1 lower derivatives of the optimum; ``zetas``: an optional dict
+    j -> zeta_j that is filled and reused across orders (one ``gemv`` per derivative).  Two passes over X per order
+    (orders 2 and 3 also have the one-pass kernels ``glm_taylor2_rhs`` / ``glm_taylor3_rhs``)."""
+    lib = dev.require_gpu()
+    _fp64_only(obj.X, "the Taylor expansion")
+    if not 2 <= k <= TAYLOR_MAX_ORDER:
+        raise NotImplementedError("Taylor orders 2..%d are built (got %d)" % (TAYLOR_MAX_ORDER, k))
+    if len(derivs) < k - 1:
+        raise ValueError("order %d needs the %d lower derivatives" % (k, k - 1))
+    mio = k if max_input_order is None else int(max_input_order)
+    zetas = {} if zetas is None else zetas
+    Z = torch.empty((k - 1, obj.N), dtype=torch.float64, device=obj.device)
+    for j in range(1, k):
+        if j not in zetas:
+            zetas[j] = gemv(obj.X, derivs[j - 1])
+        Z[j - 1].copy_(zetas[j])
+    c = torch.empty(obj.N, dtype=torch.float64, device=obj.device)
+    _lib.check(lib.vt_glm_taylor_coeff(_lib.FAMILY[obj.family], z.data_ptr(), w.contiguous().data_ptr(),
+                                       dw.contiguous().data_ptr(), Z.data_ptr(), obj.N, obj.scale, k, max(mio, 1),
+                                       obj.N, c.data_ptr(), dev.stream_ptr()), "vt_glm_taylor_coeff")
+    return gemv_t(obj.X, c)
+
+
 _tn_ws_cache = {}
 
 

@@ -302,14 +302,19 @@ class ParametricSensitivityTaylorExpansion:
     hyper-parameter.  The reference expands an arbitrary estimating equation to arbitrary order
     with nested ``autograd.make_jvp`` calls; this build covers what has a fixed kernel shape
     (SURVEY.md section 8f, rank 4): **data weights of a registered ``WeightedGLMObjective``,
-    orders 1 to 3** (any order for the gaussian family, whose higher link derivatives vanish --
-    the reference's own order-4 regression test runs), each order one streaming pass over X plus
-    one Cholesky solve:
+    orders 1 to 8** (any order for the gaussian family, whose higher link derivatives vanish --
+    the reference's own order-4 regression test runs).  Orders 1 to 3 are one fused streaming pass over X
+    plus one Cholesky solve each:
 
         d1 = -H^{-1} X^T (r .* dw)
         d2 = -H^{-1} X^T scale (w ell''' t^2 + 2 dw ell'' t),   t = X d1
 
         d3 = -H^{-1} X^T scale (w (l4 t^3 + 3 l3 t t2) + 3 dw (l3 t^2 + l2 t2)),   t2 = X d2, lk = k-th link derivative
+
+    and every higher order k is Faa di Bruno per row (``vt_glm_taylor_coeff``: partial Bell polynomials of
+    ``zeta_j = X d_j``), two passes over X (``zeta_{k-1}`` and ``X^T c``) plus the solve:
+
+        d_k = -H^{-1} X^T scale (w sum_{m=2..k} l_{m+1} B_{k,m}(zeta) + k dw sum_{m=1..k-1} l_{m+1} B_{k-1,m}(zeta))
 
     Same constructor / classmethod arguments and methods as the reference.  ``max_input_order`` truncates
     like the reference does (:1242-1249: a term whose number of partial derivatives w.r.t. the input exceeds it
@@ -350,10 +355,10 @@ class ParametricSensitivityTaylorExpansion:
             raise ValueError('max_hyper_order must be >= 1.')
         if order < 1:
             raise ValueError('order must be at least one.')
-        if order > 3 and obj.family != 'gaussian':
+        if order > rows.TAYLOR_MAX_ORDER and obj.family != 'gaussian':
             raise NotImplementedError(
-                'Taylor orders above 3 are built for the gaussian family only (its higher link '
-                'derivatives vanish); other families stop at order 3.')
+                'Taylor orders above %d are built for the gaussian family only (its higher link '
+                'derivatives vanish).' % rows.TAYLOR_MAX_ORDER)
         self._obj = obj
         self._input_val0 = deepcopy(input_val0)
         self._hyper_val0 = deepcopy(hyper_val0)
@@ -411,6 +416,15 @@ class ParametricSensitivityTaylorExpansion:
             else:               # E alone = kernel(0, dw, t2) - kernel(0, dw, 0)
                 vec = rows.glm_taylor3_rhs(obj, self._z, zero_n, dhyper, d1, d2) - \
                     rows.glm_taylor3_rhs(obj, self._z, zero_n, dhyper, d1, zeta2=zero_n)
+        elif obj.family != 'gaussian':
+            # any higher order: Faa di Bruno per row (partial Bell polynomials of zeta_j = X d_j), two passes over X;
+            # the zeta_j of the derivatives already found are kept for the next order
+            # (kept by identity: the cache holds the derivative tensors themselves, so no address is ever reused)
+            cache = getattr(self, '_zeta_cache', {})
+            zetas = {j: c[2] for j, c in cache.items()
+                     if j < k and c[0] is input_derivs[j - 1] and c[1] == input_derivs[j - 1]._version}
+            vec = rows.glm_taylor_rhs(obj, self._z, self._w, dhyper, input_derivs, k, max_input_order=mio, zetas=zetas)
+            self._zeta_cache = {j: (input_derivs[j - 1], input_derivs[j - 1]._version, zj) for j, zj in zetas.items()}
         else:
             # gaussian family: G is bilinear in (theta, w), so the order-k equation is
             # H d_k + k (d^2 G / d theta d w)[d_{k-1}, dw] = 0: one fused pass X^T (scale dw .* (X d_{k-1}))
@@ -471,6 +485,8 @@ class ParametricSensitivityTaylorExpansion:
             if k is None or order == (k - 1):
                 print('\nTerms for order {}:'.format(order + 1))
                 terms = table.get(order + 1)
+                if terms is None and nonlin:
+                    terms = _taylor_terms(order + 1)
                 if terms is None:       # gaussian family, order > 3: H d_k + k G_tw[d_{k-1}, dw]
                     eta = [0] * (order + 1)
                     eta[order] = 1
@@ -490,6 +506,35 @@ class ParametricSensitivityTaylorExpansion:
         for t in terms[1:]:
             total = total + t
         return total
+
+
+def _partitions(n, largest=None):
+    """Integer partitions of n as lists of part multiplicities a[j - 1] = how many parts equal j."""
+    largest = n if largest is None else largest
+    if n == 0:
+        yield []
+        return
+    for part in range(min(n, largest), 0, -1):
+        for rest in _partitions(n - part, part):
+            yield [part] + rest
+
+
+def _taylor_terms(k):
+    """(prefactor, eta_orders, eps_order) of every term of d^k G / d eps^k for an estimating equation linear in the
+    hyper-parameter (Faa di Bruno): a partition of k with a_j parts equal to j carries k! / prod_j (j!^a_j a_j!) and
+    the factors d^j eta, a_j times each; the terms with one hyper derivative are k times the partitions of k - 1."""
+    from math import factorial
+    out = []
+    for eps, n, lead in ((0, k, 1), (1, k - 1, k)):
+        for parts in _partitions(n):
+            a = [0] * k
+            for p_ in parts:
+                a[p_ - 1] += 1
+            coef = factorial(n)
+            for j, aj in enumerate(a, start=1):
+                coef //= factorial(j) ** aj * factorial(aj)
+            out.append((lead * coef, a, eps))
+    return out
 
 
 class _GradOf:
