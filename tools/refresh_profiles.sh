@@ -38,3 +38,4 @@ clean gpurun_out/prof/hvp_multi.txt > profiles/${P}_hvp_multi_stages.txt
   echo "# FETCH_SIZE in KB per dispatch, x2 on gfx950 for 16-B/lane LDS-DMA reads; round 2 (tile-major workgroup order): 4.09e7 KB raw = 82 GB, hit rate 2 %"
   python3 tools/pmc_summary.py $(newest syrk_fetch counter_collection.csv) k_syrk_lds
   python3 tools/pmc_summary.py $(newest syrk_hit counter_collection.csv) k_syrk_lds; } > profiles/${P}_pmc_syrk_l2.txt
+clean gpurun_out/prof/hess_tile_d.txt > profiles/${P}_hess_tile_d_stages.txt
