@@ -192,6 +192,7 @@ def test_fp32_row_operators(relerr):
     import vittles_amd as va
     for (N, D, family) in [(1000, 20, "logistic"), (513, 129, "poisson"), (3000, 1000, "gaussian"),
                            (257, 31, "logistic"), (64, 4096, "logistic"), (5000, 100, "poisson"),
+                           (300, 3001, "logistic"),     # odd D in (2048, 4096]: rows re-laid on a 16-byte pitch
                            # wide float rows (round 3: the wide team on 16-byte lanes): D > 4096, odd widths re-laid
                            (300, 4100, "logistic"), (257, 10241, "gaussian"), (200, 20000, "logistic"),
                            (130, 20447, "poisson")]:

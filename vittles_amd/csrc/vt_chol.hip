@@ -35,6 +35,10 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 
 // do_factor: factor the matrix at Ain (leading dimension ldin) into A (Ain == A: in place; otherwise A
 // also gets a zero strict upper triangle), else A already holds L;  pack != NULL: also emit the TRSM pack.
+// ASMP: the panel substitution with hand-scheduled LDS reads (below); false: the same arithmetic in the same order as
+// plain C++ (VT_POTRF_C_PANEL=1 selects it at run time; tests/test_gpu_chol.py compares the two bit for bit, so a
+// toolchain whose register allocation breaks the asm variant's in-flight-read assumption is caught).
+template <bool ASMP>
 __global__ __launch_bounds__(256) void k_potrf_pack_small(const double* Ain, int ldin, double* A, int lda, int D,
                                                          int* info, double* pack, int do_factor) {
     __shared__ double a[VT_SMALL_D_MAX * kSmallLd];
@@ -209,12 +213,13 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(const double* Ain, int
                 // became 16 dot products, each behind its own LDS round trip and with a dependent FMA chain as long
                 // as the row (D = 100: 45.1 -> 43.2 us for the kernel).  The reads are uniform (broadcast) and inline
                 // asm so that column m + 1 is in flight under the updates of column m.
-                typedef __attribute__((address_space(3))) void* ldsptr_t;
                 double t[16], rd[16];
 #pragma unroll
                 for (int m = 0; m < 16; ++m) t[m] = a[R * kSmallLd + o + m];
 #pragma unroll
                 for (int m = 0; m < 16; ++m) rd[m] = rdiag_s[o + m];
+                if constexpr (ASMP) {
+                typedef __attribute__((address_space(3))) void* ldsptr_t;
                 const unsigned lb = (unsigned)(uintptr_t)(ldsptr_t)(a + o * kSmallLd + o);   // L_JJ[0][0]
                 double Lc[2][16];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -235,6 +240,14 @@ __global__ __launch_bounds__(256) void k_potrf_pack_small(const double* Ain, int
                     t[m] *= rd[m];
 #pragma unroll
                     for (int cc = m + 1; cc < 16; ++cc) t[cc] = fma(-t[m], Lc[m & 1][cc], t[cc]);
+                }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 15; ++m) {
+                        t[m] *= rd[m];
+#pragma unroll
+                        for (int cc = m + 1; cc < 16; ++cc) t[cc] = fma(-t[m], a[(o + cc) * kSmallLd + o + m], t[cc]);
+                    }
                 }
                 t[15] *= rd[15];
 #pragma unroll
@@ -590,9 +603,17 @@ int dispatch_trsm_kl(const TrsmArgs& a, hipStream_t st) {
 
 }  // namespace
 
+static void launch_potrf_pack_small(const double* Ain, int ldin, double* A, int lda, int D, int* info, double* pack,
+                                    int do_factor, hipStream_t st) {
+    static const bool c_panel = getenv("VT_POTRF_C_PANEL") != nullptr;   // checking switch, read once per process
+    if (c_panel)
+        hipLaunchKernelGGL(k_potrf_pack_small<false>, dim3(1), dim3(256), 0, st, Ain, ldin, A, lda, D, info, pack, do_factor);
+    else
+        hipLaunchKernelGGL(k_potrf_pack_small<true>, dim3(1), dim3(256), 0, st, Ain, ldin, A, lda, D, info, pack, do_factor);
+}
+
 int vt_potrf_pack_block(double* A, int lda, int D, int* info, double* pack, int do_factor, hipStream_t st) {
-    hipLaunchKernelGGL(k_potrf_pack_small, dim3(1), dim3(256), 0, st, (const double*)A, lda, A, lda, D, info, pack,
-                       do_factor);
+    launch_potrf_pack_small((const double*)A, lda, A, lda, D, info, pack, do_factor, st);
     return vt_launch_status();
 }
 
@@ -686,7 +707,7 @@ extern "C" int vt_potrf_pack_from(const double* H, int ldh, double* L, int ldl, 
                                           (size_t)D * sizeof(double), D, hipMemcpyDeviceToDevice, st));
         return vt_potrf_pack(L, ldl, D, info, pack, stream);
     }
-    hipLaunchKernelGGL(k_potrf_pack_small, dim3(1), dim3(256), 0, st, H, ldh, L, ldl, D, info, (double*)pack, 1);
+    launch_potrf_pack_small(H, ldh, L, ldl, D, info, (double*)pack, 1, st);
     return vt_launch_status();
 }
 
