@@ -413,8 +413,37 @@ struct TileLds {   // offsets in doubles
     static constexpr int kY = kScratch + 4 * 32;          // [3][TR] y_n, [3][TR] w_n, [3][TR] offset_n of the tiles
     static constexpr int kW = kY + 3 * TR;
     static constexpr int kOff = kW + 3 * TR;
-    static constexpr int kTotal = kOff + 3 * TR;
+    static constexpr int kFlags = kOff + 3 * TR;          // [4 SIMDs][4] ints: tiles landed / linked / consumed by MFMA wave 1
+    static constexpr int kTotal = kFlags + 8;
 };
+
+// SIMD-local hand-over counters of the k-step split (each SIMD's rows are private to its three waves, so nothing
+// in the tile loop needs the workgroup-wide s_barrier): monotone counts in LDS, one writer each, polled with
+// s_sleep in between.  Every wait is bounded (a wave that gives up runs on and the results are wrong, but the grid
+// always drains).
+// Both measured (round 3, N = 10^6, D = 100): they remove stalls -- SQ_WAVE_CYCLES per launch 4.16e8 -> 4.04e8 (flags)
+// -> 3.97e8 (flags + prefetch), MFMA pipe 65.6 -> 68.7 % busy -- and the wall time stays where it was (0.243 /
+// 0.243 / 0.241 ms): the chip answers the tighter issue stream with a lower clock (2.29 -> 2.17 GHz).  Off by
+// default: the s_barrier version is the simpler program.
+#ifndef VT_TILE_FLAGS
+#define VT_TILE_FLAGS 0    // dev switch: SIMD-local hand-over counters instead of the workgroup barrier
+#endif
+#ifndef VT_TILE_PF
+#define VT_TILE_PF 0       // dev switch: operand reads one k-step ahead of the products (two register sets)
+#endif
+enum { kFlagLanded = 0, kFlagLinked = 1, kFlagDoneB = 2 };
+__device__ __forceinline__ void tile_flag_wait(unsigned addr, int target) {
+    for (int spins = 0; spins < (1 << 20); ++spins) {
+        int v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        if (__builtin_amdgcn_readfirstlane(v) >= target) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void tile_flag_set(unsigned addr, int value) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // everything this wave read or wrote in LDS is done
+    if ((threadIdx.x & 63) == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(value) : "memory");
+}
 
 // Which rows of X a workgroup's k-th tile holds (tiles are dealt round-robin over the grid).
 template <int TR>
@@ -430,7 +459,7 @@ struct TileRows {
 
 // SERVICE wave (wave group 0, one per SIMD): links the RPS rows [RPS*simd, RPS*(simd+1)) of tile p+1 in period p.
 // The tile landed a period ago: MFMA wave 0 of this SIMD issued its DMA and waited for it before the barrier.
-template <int NB, int FAM, int TURNS>
+template <int NB, int FAM, int TURNS, bool FLAGS>
 __device__ __forceinline__ void hess_tile_service(const HessArgs& a, double* lds, int64_t mine, int simd) {
     using LY = TileLds<NB>;
     constexpr int RS = LY::RS, TR = LY::TR;
@@ -497,11 +526,14 @@ __device__ __forceinline__ void hess_tile_service(const HessArgs& a, double* lds
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    vt_lds_barrier();                  // tile 0 has landed (MFMA wave 0 fetched it and waited)
+    const unsigned fl = (unsigned)(uintptr_t)(vt_ldsptr)((int*)(lds + LY::kFlags) + 4 * simd);
+    if (!FLAGS) vt_lds_barrier();      // tile 0 has landed (MFMA wave 0 fetched it and waited)
     int b1 = 0;                        // buffer of tile p+1
     for (int64_t p = -1; p < mine; ++p) {
+        if (FLAGS) tile_flag_wait(fl + 4 * kFlagLanded, (int)p + 2);      // tile p+1 is in LDS
         if (!(VT_ABL & 4)) link(p + 1, b1);
-        vt_lds_barrier();
+        if (FLAGS) tile_flag_set(fl + 4 * kFlagLinked, (int)p + 2);       // tiles 0..p+1 are linked
+        else vt_lds_barrier();
         b1 = b1 == 2 ? 0 : b1 + 1;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every tile is dead
@@ -593,52 +625,64 @@ __device__ __forceinline__ void hess_tile_mfma(const HessArgs& a, double* lds, i
     for (int i = 0; i < NOWN; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
     const unsigned strip_lane = 8u * (unsigned)(c & 3) - 8u * (unsigned)c;   // byte offset: column c -> column c & 3
 
+    constexpr bool FLAGS = KSP && VT_TILE_FLAGS;
+    const unsigned fl = (unsigned)(uintptr_t)(vt_ldsptr)((int*)(lds + LY::kFlags) + 4 * simd);
     if (ks == 0) {                     // prologue: tile 0, landed before anybody links it
         dma(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (FLAGS) tile_flag_set(fl + 4 * kFlagLanded, 1);
     }
-    vt_lds_barrier();
+    if (!FLAGS) vt_lds_barrier();
     int b0 = 2;                        // buffer of tile p (p = -1: unused)
     for (int64_t p = -1; p < mine; ++p) {
+        // the buffer of tile p+2 is the one of tile p-1: the other MFMA wave must be done with it (this one is, and
+        // the service wave linked it before either could start)
+        if (FLAGS && ks == 0) tile_flag_wait(fl + 4 * kFlagDoneB, (int)p);
         if (ks == 0 && !(VT_ABL & 8)) dma(p + 2, b0 == 0 ? 2 : b0 - 1);   // buffer (p+2) % 3 == buffer of tile p-1
+        if (FLAGS && p >= 0) tile_flag_wait(fl + 4 * kFlagLinked, (int)p + 1);   // tile p is linked: its d_n are in LDS
         if (p >= 0 && !(VT_ABL & 1)) {
             // The operand reads are inline asm: as compiler-visible LDS loads they make hipcc wait for this
             // wave's own LDS-DMA (vmcnt(0): it cannot tell the tile buffers apart).  A real loop, not unrolled:
             // its body is the whole instruction budget of the kernel.
             unsigned ta = (unsigned)(uintptr_t)(vt_ldsptr)(lds + LY::kTile + b0 * (TR * RS) + (q + 4 * kbeg) * RS + c);
             unsigned da = (unsigned)(uintptr_t)(vt_ldsptr)(lds + LY::kD + b0 * TR + q + 4 * kbeg);
-#pragma nounroll
-            for (int m = 0; m < kcnt; ++m) {
-                double xa[8];
-                double xs[2] = {0.0, 0.0};
-                double dq;
-                asm volatile("ds_read_b64 %0, %1" : "=v"(dq) : "v"(da));
+            double xa[2][8];
+            double xs[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+            double dq[2];
+            // the operand reads of one k-step (4 rows) into register set `st`
+            auto issue = [&](int st, unsigned ta_, unsigned da_) __attribute__((always_inline)) {
+                asm volatile("ds_read_b64 %0, %1" : "=v"(dq[st]) : "v"(da_));
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    if ((NEED >> b) & 1)   // column blocks this quarter's products touch
-                        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xa[b]) : "v"(ta), "n"(128 * b));
+                    if ((NEED >> b) & 1)   // column blocks this wave's products touch
+                        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xa[st][b]) : "v"(ta_), "n"(128 * b));
                     else
-                        xa[b] = 0.0;
+                        xa[st][b] = 0.0;
                 }
                 if constexpr (STRIP) {
-                    const unsigned tas = ta + strip_lane;
+                    const unsigned tas = ta_ + strip_lane;
 #pragma unroll
                     for (int s2 = 0; s2 < NS; ++s2)
-                        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xs[s2]) : "v"(tas), "n"(128 * (NB - 1) + 32 * s2));
+                        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xs[st][s2]) : "v"(tas), "n"(128 * (NB - 1) + 32 * s2));
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dq));
-                // every operand is tied to a volatile asm BEHIND the wait (volatile asms keep their order)
+            };
+            // everything issued so far has landed; every operand of set `st` is tied to a volatile asm BEHIND the wait
+            // (volatile asms keep their order)
+            auto landed = [&](int st) __attribute__((always_inline)) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dq[st]));
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
-                    if ((NEED >> b) & 1) asm volatile("" : "+v"(xa[b]));
+                    if ((NEED >> b) & 1) asm volatile("" : "+v"(xa[st][b]));
                 if constexpr (STRIP) {
 #pragma unroll
-                    for (int s2 = 0; s2 < NS; ++s2) asm volatile("" : "+v"(xs[s2]));
+                    for (int s2 = 0; s2 < NS; ++s2) asm volatile("" : "+v"(xs[st][s2]));
                 }
+            };
+            auto products = [&](int st) __attribute__((always_inline)) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     if (!((COLS >> j) & 1)) continue;
-                    const double bj = dq * xa[j];
+                    const double bj = dq[st] * xa[st][j];
 #pragma unroll
                     for (int i = j; i < NB; ++i)
                         if ((OWN >> blk_ord(NB, i, j)) & 1) {
@@ -646,22 +690,48 @@ __device__ __forceinline__ void hess_tile_mfma(const HessArgs& a, double* lds, i
                             if (NS > 0 && i == NB - 1) {
 #pragma unroll
                                 for (int s2 = 0; s2 < NS; ++s2)
-                                    ac[s2] = __builtin_amdgcn_mfma_f64_4x4x4f64(xs[s2], bj, ac[s2], 0, 0, 0);
+                                    ac[s2] = __builtin_amdgcn_mfma_f64_4x4x4f64(xs[st][s2], bj, ac[s2], 0, 0, 0);
                             } else {
-                                ac = mfma_f64(xa[i], bj, ac);
+                                ac = mfma_f64(xa[st][i], bj, ac);
                             }
                         }
                 }
-                ta += 4 * RS * 8;
-                da += 4 * 8;
-                __builtin_amdgcn_sched_barrier(0);
+            };
+            if constexpr (KSP && VT_TILE_PF) {
+                // the SIMD's few k-steps, unrolled, two operand sets in rotation: the reads of k-step m + 1 are in
+                // flight under the products of k-step m (while this wave waits for LDS the other MFMA wave of the
+                // SIMD issues alone, at less than half the pipe's rate: hardware fact 1)
+                constexpr int KC = KSTEPS / kTileNQ;
+                issue(0, ta, da);
+#pragma unroll
+                for (int m = 0; m < KC; ++m) {
+                    landed(m & 1);
+                    if (m + 1 < KC) issue((m + 1) & 1, ta + (m + 1) * (4 * RS * 8), da + (m + 1) * (4 * 8));
+                    products(m & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma nounroll
+                for (int m = 0; m < kcnt; ++m) {
+                    issue(0, ta, da);
+                    landed(0);
+                    products(0);
+                    ta += 4 * RS * 8;
+                    da += 4 * 8;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         // my DMA of tile p+2, issued a whole period ago in wall time: landed before the barrier, so the service
         // wave may link it in the next period
         if (ks == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        vt_lds_barrier();
+        if (FLAGS) {
+            if (ks == 0) tile_flag_set(fl + 4 * kFlagLanded, (int)p + 3);        // tiles 0..p+2 are in LDS
+            else tile_flag_set(fl + 4 * kFlagDoneB, (int)p + 1);                 // tiles 0..p are consumed
+        } else {
+            vt_lds_barrier();
+        }
         b0 = b0 == 2 ? 0 : b0 + 1;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every tile is dead
@@ -705,6 +775,7 @@ __global__ __launch_bounds__(kTileThreads) void k_glm_hess_tile(HessArgs a) {
     extern __shared__ double lds[];
     for (int t = threadIdx.x; t < NB * 16; t += kTileThreads) lds[LY::kTheta + t] = t < a.D ? a.theta[t] : 0.0;
     for (int t = threadIdx.x; t < 4 * 32; t += kTileThreads) lds[LY::kScratch + t] = 0.0;
+    for (int t = threadIdx.x; t < 8; t += kTileThreads) lds[LY::kFlags + t] = 0.0;
     __syncthreads();
     const int64_t ntiles = (a.N + LY::TR - 1) / LY::TR;
     const int64_t mine = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
@@ -712,7 +783,7 @@ __global__ __launch_bounds__(kTileThreads) void k_glm_hess_tile(HessArgs a) {
     const int simd = wid & 3, grp = wid >> 2;
     constexpr bool KSP = tile_ksplit(NB);
     if (grp == 0) {
-        hess_tile_service<NB, FAM, KSP ? kTileNQ : kTileNM>(a, lds, mine, simd);
+        hess_tile_service<NB, FAM, KSP ? kTileNQ : kTileNM, KSP && VT_TILE_FLAGS>(a, lds, mine, simd);
     } else if constexpr (KSP) {
         static_assert(!KSP || kTileNM == 2, "two MFMA waves per SIMD split the triangle");
         if (grp == 1) hess_tile_mfma<NB, NS, 0, true>(a, lds, mine, 0, simd);    // part = MFMA wave
@@ -736,7 +807,7 @@ __global__ __launch_bounds__(kTileThreads) void k_glm_hess_tile(HessArgs a) {
 }
 
 inline size_t tile_lds_bytes(int NB) {
-    const size_t loop = (size_t)3 * tile_rows(NB) * tile_rs(NB) + 12 * tile_rows(NB) + NB * 16 + 4 * 32;
+    const size_t loop = (size_t)3 * tile_rows(NB) * tile_rs(NB) + 12 * tile_rows(NB) + NB * 16 + 4 * 32 + 8;
     const size_t tail = (size_t)NB * (NB + 1) / 2 * 256 + 4 * NB * 16;
     return std::max(loop, tail) * sizeof(double);
 }
