@@ -26,6 +26,7 @@
 //   * the last block row is computed with 4x4x4 MFMA strips when D mod 16 <= 8 (as in the tile kernel), so
 //     D = 129 costs 8 full block rows + one 4-row strip, not 9 block rows.
 #include "vt_common.h"
+#include <algorithm>
 #include <cstdlib>
 
 #ifndef VT_MID_LINK_DELTA
@@ -464,12 +465,14 @@ int launch_mid(const MidArgs& a, int grid, hipStream_t st) {
 
 bool vt_hess_mid_ok(const double* X, int64_t ldx, int D) {
     static const bool off = getenv("VT_HESS_NO_MID") != nullptr;   // dev A/B switch, read once
-    return !off && D > VT_SMALL_D_MAX && D <= VT_MID_D_MAX && ldx % 2 == 0 && ((uintptr_t)X % 16 == 0) &&
+    // dev switch: the smallest D the owner-wave kernel takes (default: above what the 12-wave tile kernel covers)
+    static const int dmin = getenv("VT_HESS_MID_MIN_D") ? atoi(getenv("VT_HESS_MID_MIN_D")) : VT_SMALL_D_MAX + 1;
+    return !off && D >= std::max(dmin, 113) && D <= VT_MID_D_MAX && ldx % 2 == 0 && ((uintptr_t)X % 16 == 0) &&
            ldx <= ((int64_t)1 << 27);
 }
 
 size_t vt_hess_mid_ws_bytes(int D) {
-    if (D <= VT_SMALL_D_MAX || D > VT_MID_D_MAX) return 0;
+    if (D < 113 || D > VT_MID_D_MAX) return 0;
     const int NB = (D + 15) / 16;
     return (size_t)vt_num_cu() * (NB * (NB + 1) / 2 * 256 + NB * 16) * sizeof(double);
 }
@@ -488,6 +491,7 @@ int vt_hess_mid(int family, const double* X, int64_t ldx, const double* theta, c
 #ifdef VT_MID_DEVNB
         case VT_MID_DEVNB: rc = launch_mid<VT_MID_DEVNB>(a, grid, st); break;
 #else
+        case 8: rc = launch_mid<8>(a, grid, st); break;
         case 9: rc = launch_mid<9>(a, grid, st); break;
         case 10: rc = launch_mid<10>(a, grid, st); break;
         case 11: rc = launch_mid<11>(a, grid, st); break;
