@@ -357,6 +357,7 @@ struct TrsmArgs {
     double* Out;
     int64_t ldo;
     int mode;   // 0: full solve (L L^T)^{-1};  1: forward only  L^{-1};  2: backward only  L^{-T}
+    int rev;    // walk the row tiles from the last one down (see launch_trsm)
 };
 
 // Out[n,:] = alpha * s_n * (L L^T)^{-1} B[n,:].   D <= 128.
@@ -479,9 +480,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
     f64x4 Gn[PF][NB];
     double coefn[PF];
 
+    const int64_t last = ngroups - 1;       // (groups past the end re-read the last one: loaded, never used)
     // Unconditional loads with clamped indices (no branch per load): rows past N
     // re-read row N-1 and are zeroed through coef = 0.
     auto load_group = [&](int64_t grp, f64x4 (&G)[NB], double& coef) {
+        if (a.rev) grp = last - grp;
         int64_t row = grp * 16 + n;
         bool rowok = row < a.N;
         int64_t rowc = rowok ? row : a.N - 1;
@@ -515,7 +518,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
 
     constexpr bool PREFETCH = WAVES <= 8;   // more waves per SIMD: no register room for (nor need of) a prefetched tile
     int64_t grp = gw;
-    const int64_t last = ngroups - 1;       // (groups past the end re-read the last one: loaded, never used)
     if constexpr (PREFETCH) {
 #pragma unroll
         for (int f = 0; f < PF; ++f) load_group(min(grp + f * W, last), Gn[f], coefn[f]);
@@ -533,6 +535,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_small(TrsmArgs a) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) st.V[b] = G[b] * coef;
         if constexpr (PREFETCH) load_group(min(g + PF * W, last), G, coef);
+        if (a.rev) g = last - g;
         int64_t row = g * 16 + n;
         const bool rowok = row < a.N;
         st.store_fwd = rowok && a.mode == 1;
@@ -620,7 +623,10 @@ int vt_potrf_pack_block(double* A, int lda, int D, int* info, double* pack, int 
 int vt_trsm_rows_mode(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
                       int64_t N, double* Out, int64_t ldo, int mode, hipStream_t st) {
     if (N == 0) return VT_OK;
-    TrsmArgs a{(const double*)pack, B, ldb, rowscale, alpha, N, D, Out, ldo, mode};
+    // Row tiles from the last one down: the pass that produced H (and, in a loop of steps, the next one) walks X from
+    // the first row up, so the rows it touched last are the ones still in the 256 MB memory-side cache.
+    static const bool fwd_order = getenv("VT_TRSM_ASCENDING") != nullptr;   // dev A/B switch, read once
+    TrsmArgs a{(const double*)pack, B, ldb, rowscale, alpha, N, D, Out, ldo, mode, fwd_order ? 0 : 1};
     switch ((D + 15) / 16) {
         case 1: dispatch_trsm_kl<1>(a, st); break;
         case 2: dispatch_trsm_kl<2>(a, st); break;
