@@ -201,8 +201,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_f32(Trsm32Args a) {
 
     f32x4 Gn[NB];
     float coefn;
+    // the row tiles are walked from the last one down (like k_trsm_rows_small: the rows the Hessian pass read last are
+    // the ones still in the memory-side cache -- 0.4 GB of float X at the headline shape, 256 MB of cache)
     auto load_group = [&](int64_t grp) {
-        const int64_t row = grp * 16 + n;
+        const int64_t row = (ngroups - 1 - grp) * 16 + n;
         const bool rowok = row < a.N;
         const int64_t rowc = rowok ? row : a.N - 1;
         const float* br = a.B + rowc * a.ldb;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_trsm_rows_f32(Trsm32Args a) {
     for (; grp < ngroups; grp += W) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) st.V[b] = Gn[b] * coefn;
-        const int64_t row = grp * 16 + n;
+        const int64_t row = (ngroups - 1 - grp) * 16 + n;
         st.store = row < a.N;
         st.orow = a.Out + (st.store ? row : 0) * a.ldo;
         load_group(grp + W < ngroups ? grp + W : grp);
