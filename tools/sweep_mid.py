@@ -8,7 +8,9 @@ from vittles_amd.linalg import DeviceCholesky
 
 
 def timeit(fn, reps=10):
-    fn(); torch.cuda.synchronize()
+    for _ in range(10):      # the clock needs a few ms of load to settle (the first D of a sweep read 20 % slow with one call)
+        fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
