@@ -94,7 +94,8 @@ def test_fused_hessian_grad_mid(N, D, family, relerr):
 
 @pytest.mark.parametrize("N,D,family", [(4096, 129, "logistic"), (5000, 160, "poisson"), (4321, 192, "gaussian"),
                                          (6000, 255, "logistic"), (4200, 256, "logistic"), (4100, 145, "gaussian"),
-                                         (4500, 216, "poisson")])
+                                         (4500, 216, "poisson"), (4300, 273, "logistic"), (5000, 320, "poisson"),
+                                         (4100, 322, "gaussian")])
 def test_sensitivity_mid_d(N, D, family, relerr):
     """D in {129, 160, 192, 255} x N >= 4096 through the drop-in class vs the oracle."""
     from oracle import glm
@@ -110,10 +111,13 @@ def test_sensitivity_mid_d(N, D, family, relerr):
     assert relerr(sens.get_dopt_dhyper(), S_ref) < TOL
 
 
-# the chain kernels of csrc/vt_trsm_mid.h directly: every block count NB = 9..16 with every last-block class
-# (1..4, 5..8, 9..15, 16 columns), one / ragged / many tiles, odd row pitches, in place
+# the chain kernels of csrc/vt_trsm_mid.h directly: every block count NB = 9..20 with every last-block class
+# (1..4, 5..8, 9..15, 16 columns), one / ragged / many tiles, odd row pitches, in place; past 320 columns the blocked
+# solve on 320-column diagonal blocks (forward-only / backward-only halves of the NB = 20 chain + GEMM-NT updates)
 @pytest.mark.parametrize("D", [129, 133, 137, 144, 145, 150, 158, 160, 161, 166, 171, 176, 178, 185, 190, 192, 193,
-                               200, 207, 208, 212, 216, 223, 224, 228, 231, 239, 240, 241, 247, 255, 256])
+                               200, 207, 208, 212, 216, 223, 224, 228, 231, 239, 240, 241, 247, 255, 256,
+                               257, 261, 266, 272, 273, 280, 284, 288, 289, 296, 300, 304, 305, 311, 316, 320,
+                               321, 400, 449, 640, 641, 700])
 def test_trsm_rows_mid(D, relerr):
     import torch
     from vittles_amd.linalg import DeviceCholesky
@@ -122,7 +126,7 @@ def test_trsm_rows_mid(D, relerr):
     H = A.T @ A / D + np.eye(D)
     cf = scipy.linalg.cho_factor(H)
     chol = DeviceCholesky.factor(torch.tensor(H, device="cuda"), pack=True)
-    for N, pad in [(1, 0), (17, 1), (4096 + D, 0), (40000 + D, 3)]:
+    for N, pad in [(1, 0), (17, 1), (4096 + D, 0), (40000 + D if D <= 320 else 9000 + D, 3)]:
         B = rng.standard_normal((N, D + pad))
         s = 0.5 + rng.random(N)
         Bd = torch.tensor(B, device="cuda")[:, :D]

@@ -1,8 +1,9 @@
-// Mid-range (129 <= D <= 256) TRSM: operand pack in CHAIN ORDER and the dispatch over the chain kernels of
-// vt_trsm_mid.h (instantiated in vt_trsm_mid_{a,b,c}.hip).  Replaces the same reference lines as vt_chol.hip
+// Mid-range (129 <= D <= 320) TRSM: operand pack in CHAIN ORDER and the dispatch over the chain kernels of
+// vt_trsm_mid.h (instantiated in vt_trsm_mid_{a,b,c,e,f,g,h}.hip; the halves of a full block in _d).  Replaces the same reference lines as vt_chol.hip
 // (scipy.linalg.cho_solve with N right-hand sides, vittles/solver_lib.py:28-29, vittles/sensitivity_lib.py:226).
 #include "vt_common.h"
 #include "vt_trsm_sched.h"
+#include <algorithm>
 #include <cstdlib>
 
 int vt_mid_trsm_a(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
@@ -11,6 +12,12 @@ int vt_mid_trsm_b(const void* pack, int D, const double* B, int64_t ldb, const d
                   int64_t N, double* Out, int64_t ldo, hipStream_t st);
 int vt_mid_trsm_c(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
                   int64_t N, double* Out, int64_t ldo, hipStream_t st);
+
+#define VT_MID_DECL(X)                                                                                              \
+    int vt_mid_trsm_##X(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha, \
+                        int64_t N, double* Out, int64_t ldo, hipStream_t st);
+VT_MID_DECL(e) VT_MID_DECL(f) VT_MID_DECL(g) VT_MID_DECL(h)   // NB = 17, 18, 19, 20
+#undef VT_MID_DECL
 
 int vt_mid_trsm_d(const void* pack, const double* B, int64_t ldb, const double* rowscale, double alpha, int64_t N,
                   double* Out, int64_t ldo, int mode, hipStream_t st);
@@ -92,7 +99,7 @@ inline int mid_images(int D) {
 
 }  // namespace
 
-// mode 0: full solve (any 129 <= D <= 256); 1 / 2: forward-only / backward-only (D = 256 only)
+// mode 0: full solve (any 129 <= D <= 320); 1 / 2: forward-only / backward-only (D = VT_MID_D_MAX = 256 only)
 int vt_mid_trsm_rows_mode(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
                           int64_t N, double* Out, int64_t ldo, int mode, hipStream_t st) {
     if (mode == 0) return vt_mid_trsm_rows(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
@@ -101,9 +108,14 @@ int vt_mid_trsm_rows_mode(const void* pack, int D, const double* B, int64_t ldb,
     return vt_mid_trsm_d(pack, B, ldb, rowscale, alpha, N, Out, ldo, mode, st);
 }
 
+// The one-pass chain holds a 16 x D tile of right-hand sides per wave: 8 D / 16 + ~60 registers of the 256 a wave has
+// at two waves per SIMD, so it reaches past the Hessian kernels' D <= VT_MID_D_MAX, to NB = 20 (226 VGPRs, no spill;
+// NB = 24 spills).
+constexpr int kMidTrsmDMax = VT_TRSM_ONEPASS_D_MAX;
 bool vt_mid_trsm_ok(int D) {
-    static const bool off = getenv("VT_TRSM_NO_MID") != nullptr;   // dev A/B switch, read once
-    return !off && D > VT_SMALL_D_MAX && D <= VT_MID_D_MAX;
+    static const bool off = getenv("VT_TRSM_NO_MID") != nullptr;   // dev A/B switches, read once
+    static const int dmax = getenv("VT_TRSM_MID_MAX_D") ? atoi(getenv("VT_TRSM_MID_MAX_D")) : kMidTrsmDMax;
+    return !off && D > VT_SMALL_D_MAX && D <= std::min(dmax, kMidTrsmDMax);
 }
 
 // [chain-order images | Linv blocks]; the image area doubles as the scratch of the blocked factorisation
@@ -128,5 +140,12 @@ int vt_mid_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, cons
     const int NB = (D + 15) / 16;
     if (NB <= 12) return vt_mid_trsm_a(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
     if (NB <= 14) return vt_mid_trsm_b(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
-    return vt_mid_trsm_c(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
+    if (NB <= 16) return vt_mid_trsm_c(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
+    switch (NB) {
+        case 17: return vt_mid_trsm_e(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
+        case 18: return vt_mid_trsm_f(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
+        case 19: return vt_mid_trsm_g(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
+        case 20: return vt_mid_trsm_h(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
+    }
+    return VT_ERR_UNSUPPORTED;
 }
