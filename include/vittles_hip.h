@@ -64,7 +64,7 @@ extern "C" {
 #define VT_SMALL_D_MAX 128
 /* VT_SMALL_D_MAX < D <= VT_MID_D_MAX: one-pass kernels with the block triangle / the solve chain dealt over the
  * waves of a workgroup (csrc/vt_hess_mid.hip, csrc/vt_trsm_mid.hip); beyond, the 128 x 128 tiled kernels (the
- * one-pass solve chain itself reaches D = 320: its tile of right-hand sides still fits a wave's registers). */
+ * one-pass solve chain itself reaches D = 384: its tile of right-hand sides still fits a wave's registers). */
 #define VT_MID_D_MAX 256
 #define VT_DENSE_D_MAX 8192
 #define VT_ROWS_D_MAX  20448

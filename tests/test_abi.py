@@ -44,8 +44,11 @@ def test_workspace_queries_need_no_gpu():
     # mid range: at least the NB (NB + 1) chain-order images and the NB inverted diagonal blocks
     assert lib.vt_trsm_pack_bytes(129) >= (9 * 10 + 9) * 256 * 8
     assert lib.vt_trsm_pack_bytes(256) >= (16 * 17 + 16) * 256 * 8
-    # beyond: L and L^T images with the even leading dimension 258, and the chain packs of two 256-column blocks
-    assert lib.vt_trsm_pack_bytes(257) >= (2 * 257 * 258 + 2 * (16 * 17 + 16) * 256) * 8
+    # the one-pass chain reaches D = 384 (NB = 24)
+    assert lib.vt_trsm_pack_bytes(257) >= (17 * 18 + 17) * 256 * 8
+    assert lib.vt_trsm_pack_bytes(384) >= (24 * 25 + 24) * 256 * 8
+    # beyond: L and L^T images with the even leading dimension 386, and the chain packs of two 384-column blocks
+    assert lib.vt_trsm_pack_bytes(385) >= (2 * 385 * 386 + 2 * (24 * 25 + 24) * 256) * 8
     assert lib.vt_trsm_pack_bytes(8193) == 0         # outside what the dense kernels cover
     assert lib.vt_potrf_workspace_bytes(100) >= 0
 

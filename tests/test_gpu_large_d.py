@@ -111,13 +111,14 @@ def test_sensitivity_mid_d(N, D, family, relerr):
     assert relerr(sens.get_dopt_dhyper(), S_ref) < TOL
 
 
-# the chain kernels of csrc/vt_trsm_mid.h directly: every block count NB = 9..20 with every last-block class
-# (1..4, 5..8, 9..15, 16 columns), one / ragged / many tiles, odd row pitches, in place; past 320 columns the blocked
-# solve on 320-column diagonal blocks (forward-only / backward-only halves of the NB = 20 chain + GEMM-NT updates)
+# the chain kernels of csrc/vt_trsm_mid.h directly: every block count NB = 9..24 with every last-block class
+# (1..4, 5..8, 9..15, 16 columns), one / ragged / many tiles, odd row pitches, in place; past 384 columns the blocked
+# solve on 384-column diagonal blocks (forward-only / backward-only halves of the NB = 24 chain + GEMM-NT updates)
 @pytest.mark.parametrize("D", [129, 133, 137, 144, 145, 150, 158, 160, 161, 166, 171, 176, 178, 185, 190, 192, 193,
                                200, 207, 208, 212, 216, 223, 224, 228, 231, 239, 240, 241, 247, 255, 256,
                                257, 261, 266, 272, 273, 280, 284, 288, 289, 296, 300, 304, 305, 311, 316, 320,
-                               321, 400, 449, 640, 641, 700])
+                               321, 330, 336, 337, 345, 352, 360, 368, 369, 380, 384,
+                               385, 400, 449, 640, 641, 700, 768, 769, 800])
 def test_trsm_rows_mid(D, relerr):
     import torch
     from vittles_amd.linalg import DeviceCholesky
@@ -126,7 +127,7 @@ def test_trsm_rows_mid(D, relerr):
     H = A.T @ A / D + np.eye(D)
     cf = scipy.linalg.cho_factor(H)
     chol = DeviceCholesky.factor(torch.tensor(H, device="cuda"), pack=True)
-    for N, pad in [(1, 0), (17, 1), (4096 + D, 0), (40000 + D if D <= 320 else 9000 + D, 3)]:
+    for N, pad in [(1, 0), (17, 1), (4096 + D, 0), (40000 + D if D <= 384 else 9000 + D, 3)]:
         B = rng.standard_normal((N, D + pad))
         s = 0.5 + rng.random(N)
         Bd = torch.tensor(B, device="cuda")[:, :D]

@@ -194,10 +194,10 @@ int vt_large_pack(const double* L, int ldl, int D, void* pack, hipStream_t st);
 int vt_large_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
                        int64_t N, double* Out, int64_t ldo, hipStream_t st);
 // The one-pass solve chain (vt_trsm_mid.h) takes D <= VT_TRSM_ONEPASS_D_MAX: a wave holds a 16 x D tile of right-hand
-// sides in registers (NB = 20: 226 VGPRs at two waves per SIMD; NB = 24 spills).  Past it the blocked solve
-// (vt_large.hip) keeps diagonal blocks of VT_MID_D_MAX = 256 columns: its GEMM-NT updates work on 128-column tiles
-// (320-column blocks were measured: D = 1000 48.9 -> 56.9 ms, 2.5 tiles per block).
-#define VT_TRSM_ONEPASS_D_MAX 320
+// sides in registers (NB = 24: the 256 VGPRs of a wave at two waves per SIMD, 9 spilled).  Past it the blocked solve
+// (vt_large.hip) uses diagonal blocks of that width -- 384 = three of the GEMM-NT updates' 128-column tiles (320-column
+// blocks were measured: D = 1000 48.9 -> 56.9 ms, 2.5 tiles per block).
+#define VT_TRSM_ONEPASS_D_MAX 384
 bool vt_mid_trsm_ok(int D);
 size_t vt_mid_pack_bytes(int D);
 int vt_mid_pack(const double* L, int ldl, int D, void* pack, hipStream_t st);

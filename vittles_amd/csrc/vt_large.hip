@@ -756,13 +756,14 @@ int vt_large_potrf(double* A, int lda, int D, int* info, void* ws, hipStream_t s
 }
 
 // ---- blocked solve, D > 256 -----------------------------------------------------------------------------------
-// Diagonal blocks of kBW = 256 columns, solved by the chain kernels of vt_trsm_mid.h (a full block: forward-only /
+// Diagonal blocks of kBW = 384 columns (256 until the one-pass chain reached NB = 24), solved by the chain kernels
+// of vt_trsm_mid.h (a full block: forward-only /
 // backward-only halves; the last, partial block: the whole chain of vt_trsm_mid / vt_chol), off-diagonal panels
 // by GEMM-NT updates.  Round 2 used 128-column blocks and the small chain: twice the sweeps over S (each an
 // HBM-bound read + write of N x 128) and twice the update launches; a 256-column block does 4x the MFMA work per
 // byte of its sweep (MFMA-bound at 73 % of peak) and moves a quarter of the flops out of the GEMM.
 // Pack: [Lc | LT | one chain pack per 256-column block].  VT_TRSM_NO_MID=1 keeps the 128-column scheme (dev A/B).
-constexpr int kBW = VT_MID_D_MAX;
+constexpr int kBW = VT_TRSM_ONEPASS_D_MAX;
 static bool wide_blocks() { return vt_mid_trsm_ok(kBW); }
 static size_t wide_pack_stride() {   // doubles per block pack: the larger of a chain pack and a small pack
     return (std::max(vt_mid_pack_bytes(kBW), (size_t)kPackStride * sizeof(double)) + 255) / 256 * 256 / sizeof(double);

@@ -316,6 +316,9 @@ template <int NB>
 int midt_dispatch(const MidTrsmArgs& a, hipStream_t st) {
     const int rem = a.D - 16 * (NB - 1);   // 1..16 columns in the last block
     if (rem == 16) return midt_launch<NB, 4, true>(a, st);
+    // NB >= 17: one variant for every partial last block (its all-zero k-steps are computed: 1 / NB of the chain's
+    // last block row; the strip variants would double the build time of these long schedules)
+    if constexpr (NB >= 17) return midt_launch<NB, 4, false>(a, st);
     switch ((rem + 3) / 4) {
         case 1: return midt_launch<NB, 1, false>(a, st);
         case 2: return midt_launch<NB, 2, false>(a, st);

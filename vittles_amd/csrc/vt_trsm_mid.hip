@@ -1,5 +1,5 @@
-// Mid-range (129 <= D <= 320) TRSM: operand pack in CHAIN ORDER and the dispatch over the chain kernels of
-// vt_trsm_mid.h (instantiated in vt_trsm_mid_{a,b,c,e,f,g,h}.hip; the halves of a full block in _d).  Replaces the same reference lines as vt_chol.hip
+// Mid-range (129 <= D <= 384) TRSM: operand pack in CHAIN ORDER and the dispatch over the chain kernels of
+// vt_trsm_mid.h (instantiated in vt_trsm_mid_{a,b,c,e,f,g,h,i,j}.hip; the halves of a full block in _d).  Replaces the same reference lines as vt_chol.hip
 // (scipy.linalg.cho_solve with N right-hand sides, vittles/solver_lib.py:28-29, vittles/sensitivity_lib.py:226).
 #include "vt_common.h"
 #include "vt_trsm_sched.h"
@@ -16,7 +16,7 @@ int vt_mid_trsm_c(const void* pack, int D, const double* B, int64_t ldb, const d
 #define VT_MID_DECL(X)                                                                                              \
     int vt_mid_trsm_##X(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha, \
                         int64_t N, double* Out, int64_t ldo, hipStream_t st);
-VT_MID_DECL(e) VT_MID_DECL(f) VT_MID_DECL(g) VT_MID_DECL(h)   // NB = 17, 18, 19, 20
+VT_MID_DECL(e) VT_MID_DECL(f) VT_MID_DECL(g) VT_MID_DECL(h) VT_MID_DECL(i) VT_MID_DECL(j)   // NB = 17-18, 19-20, 21, 22, 23, 24
 #undef VT_MID_DECL
 
 int vt_mid_trsm_d(const void* pack, const double* B, int64_t ldb, const double* rowscale, double alpha, int64_t N,
@@ -99,18 +99,18 @@ inline int mid_images(int D) {
 
 }  // namespace
 
-// mode 0: full solve (any 129 <= D <= 320); 1 / 2: forward-only / backward-only (D = VT_MID_D_MAX = 256 only)
+// mode 0: full solve (any 129 <= D <= 384); 1 / 2: forward-only / backward-only (D = VT_TRSM_ONEPASS_D_MAX only)
 int vt_mid_trsm_rows_mode(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
                           int64_t N, double* Out, int64_t ldo, int mode, hipStream_t st) {
     if (mode == 0) return vt_mid_trsm_rows(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
-    if (D != VT_MID_D_MAX) return VT_ERR_UNSUPPORTED;
+    if (D != VT_TRSM_ONEPASS_D_MAX) return VT_ERR_UNSUPPORTED;
     if (N == 0) return VT_OK;
     return vt_mid_trsm_d(pack, B, ldb, rowscale, alpha, N, Out, ldo, mode, st);
 }
 
 // The one-pass chain holds a 16 x D tile of right-hand sides per wave: 8 D / 16 + ~60 registers of the 256 a wave has
-// at two waves per SIMD, so it reaches past the Hessian kernels' D <= VT_MID_D_MAX, to NB = 20 (226 VGPRs, no spill;
-// NB = 24 spills).
+// at two waves per SIMD, so it reaches past the Hessian kernels' D <= VT_MID_D_MAX, to NB = 24 (NB = 20: 226 VGPRs;
+// NB = 24: all 256 and 9 spilled -- still the fastest solve of the library: 79 % of the fp64-MFMA peak at D = 384).
 constexpr int kMidTrsmDMax = VT_TRSM_ONEPASS_D_MAX;
 bool vt_mid_trsm_ok(int D) {
     static const bool off = getenv("VT_TRSM_NO_MID") != nullptr;   // dev A/B switches, read once
@@ -142,10 +142,12 @@ int vt_mid_trsm_rows(const void* pack, int D, const double* B, int64_t ldb, cons
     if (NB <= 14) return vt_mid_trsm_b(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
     if (NB <= 16) return vt_mid_trsm_c(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
     switch (NB) {
-        case 17: return vt_mid_trsm_e(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
-        case 18: return vt_mid_trsm_f(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
-        case 19: return vt_mid_trsm_g(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
-        case 20: return vt_mid_trsm_h(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
+        case 17: case 18: return vt_mid_trsm_e(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
+        case 19: case 20: return vt_mid_trsm_f(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
+        case 21: return vt_mid_trsm_g(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
+        case 22: return vt_mid_trsm_h(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
+        case 23: return vt_mid_trsm_i(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
+        case 24: return vt_mid_trsm_j(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
     }
     return VT_ERR_UNSUPPORTED;
 }
