@@ -25,6 +25,7 @@ timeout -k 10 200 python3 $R/tools/time_hvp32.py 100000 20000 >> $O/fp32_stages.
 timeout -k 10 200 python3 $R/tools/time_hess_only.py 1000000 81 88 96 100 104 112 128 > $O/hess_tile_d.txt 2>&1 || exit 15
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mid_trace -- python3 $R/tools/sweep_mid.py 2000000 128 129 144 160 192 224 256 257 320 384 512 > $O/mid_profiled.log 2>&1 || exit 16
 timeout -k 10 300 python3 $R/tools/sweep_mid.py 2000000 128 129 144 160 192 224 256 257 320 384 512 > $O/mid.log 2>&1 || exit 16
+timeout -k 10 300 python3 $R/tools/sweep_mid.py 2000000 257 288 320 352 384 385 400 512 640 768 > $O/d257_768.txt 2>&1 || exit 16
 timeout -k 10 300 python3 $R/tools/time_hvp_multi.py 100000 20000 4 8 16 32 64 128 > $O/hvp_multi.txt 2>&1 || exit 17
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/syrk_fetch -- python3 $R/tools/time_syrk_only.py 1250000 1000 > $O/syrk_fetch.log 2>&1 || exit 18
 timeout -s KILL 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/syrk_hit -- python3 $R/tools/time_syrk_only.py 1250000 1000 > $O/syrk_hit.log 2>&1 || exit 19

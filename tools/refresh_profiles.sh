@@ -39,3 +39,4 @@ clean gpurun_out/prof/hvp_multi.txt > profiles/${P}_hvp_multi_stages.txt
   python3 tools/pmc_summary.py $(newest syrk_fetch counter_collection.csv) k_syrk_lds
   python3 tools/pmc_summary.py $(newest syrk_hit counter_collection.csv) k_syrk_lds; } > profiles/${P}_pmc_syrk_l2.txt
 clean gpurun_out/prof/hess_tile_d.txt > profiles/${P}_hess_tile_d_stages.txt
+clean gpurun_out/prof/d257_768.txt > profiles/${P}_d257_768_stages.txt
