@@ -934,11 +934,73 @@ extern "C" int vt_glm_grad(int family, const double* X, int64_t ldx, const doubl
 // D > 128: link + gradient by the row-streaming kernel (one pass), then the tiled SYRK.
 static size_t large_ws_rows(int D) { return (vt_rows_workspace_bytes(D) + 255) / 256 * 256; }
 
+// ---- 256 < D <= kSplitDMax: the one-pass kernel on the first 256 columns + a strip product -------------------------
+// The accumulators of a one-pass kernel stop fitting at D = 256 and the tiled SYRK pays a stage loop of its own for
+// every partial tile row (D = 257: 30 % of peak).  In between:  with X = [X1 | X2], X1 the first 256 columns,
+//   z = X1 theta1 + (X2 theta2 + offset)        -> k_glm_hess_mid on X1 with the bracket as its offset: H11, g1, r, d
+//   [H21 | H22] = X2^T diag(d) [X1 | X2]        -> vt_gemm_tn (the rectangular MFMA product, split over N)
+//   g2 = X2^T (w .* r)                          -> vt_gemm_t2's row kernel
+// 2.1 passes over X instead of the tiled route's ~3 panel reads; N = 2e6: D = 257 5.5 -> 4.1 ms, 320 6.1 -> 4.9,
+// 352 6.6 -> 5.8 (beyond, the strip's MFMA work catches up with the tiled route).  VT_HESS_NO_SPLIT=1: dev A/B switch.
+extern "C" int vt_gemv(const double* X, int64_t ldx, const double* v, int64_t N, int D, double* out, void* ws,
+                       size_t ws_bytes, void* stream);
+extern "C" int vt_gemv_t2(const double* X, int64_t ldx, const double* u1, const double* u2, int64_t N, int D,
+                          double* out, void* ws, size_t ws_bytes, void* stream);
+constexpr int kSplitDMax = 352;
+
+__global__ __launch_bounds__(256) void k_add_vec(double* a, const double* b, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] += b[i];
+}
+// H[0:D1, D1:D] <- (H[D1:D, 0:D1])^T, prior on the diagonal of the corner, g2 += prior2 .* theta2
+__global__ __launch_bounds__(256) void k_split_finish(double* H, int ldh, int D1, int D, const double* prior,
+                                                      const double* theta, double* g) {
+    const int t = D - D1;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < t * D1; e += gridDim.x * blockDim.x) {
+        const int i = e / D1, j = e - i * D1;
+        H[(int64_t)j * ldh + D1 + i] = H[(int64_t)(D1 + i) * ldh + j];
+    }
+    // the corner came out of a general product (a_i * (d b_j) and a_j * (d b_i) round differently): keep its lower
+    // triangle, so that H is exactly symmetric like every other route's
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < t * t; e += gridDim.x * blockDim.x) {
+        const int i = e / t, j = e - i * t;
+        if (j > i) H[(int64_t)(D1 + i) * ldh + D1 + j] = H[(int64_t)(D1 + j) * ldh + D1 + i];
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < t && prior) {
+        const int i = D1 + threadIdx.x;
+        H[(int64_t)i * ldh + i] += prior[i];
+        if (g) g[i] += prior[i] * theta[i];
+    }
+}
+
+static bool hess_split_ok(const double* X, int64_t ldx, int D) {
+    static const bool off = getenv("VT_HESS_NO_SPLIT") != nullptr;
+    return !off && D > VT_MID_D_MAX && D <= kSplitDMax && vt_hess_mid_ok(X, ldx, VT_MID_D_MAX);
+}
+struct SplitWs { size_t slabs, off, rtmp, dtmp, g2, rows, tn, total; };
+static SplitWs hess_split_ws(int64_t N, int D) {
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    SplitWs w{};
+    const int t = D - VT_MID_D_MAX;
+    size_t o = 0;
+    w.slabs = o; o += up(vt_hess_mid_ws_bytes(VT_MID_D_MAX));
+    w.off = o;   o += up((size_t)N * sizeof(double));
+    w.rtmp = o;  o += up((size_t)N * sizeof(double));
+    w.dtmp = o;  o += up((size_t)N * sizeof(double));
+    w.g2 = o;    o += up((size_t)kSplitDMax * sizeof(double));
+    w.rows = o;  o += up(vt_rows_workspace_bytes(t));
+    w.tn = o;    o += up(vt_gemm_tn_workspace_bytes(t, D));
+    w.total = o;
+    return w;
+}
+
 extern "C" size_t vt_glm_hessian_workspace_bytes(int64_t N, int D) {
     if (D < 1) return 0;
-    if (D > VT_SMALL_D_MAX)
-        return std::max(large_ws_rows(D) + (size_t)(N + D + 64) * sizeof(double) + vt_large_syrk_ws_bytes(D),
-                        vt_hess_mid_ws_bytes(D));
+    if (D > VT_SMALL_D_MAX) {
+        size_t b = std::max(large_ws_rows(D) + (size_t)(N + D + 64) * sizeof(double) + vt_large_syrk_ws_bytes(D),
+                            vt_hess_mid_ws_bytes(D));
+        if (D > VT_MID_D_MAX && D <= kSplitDMax) b = std::max(b, hess_split_ws(N, D).total);
+        return b;
+    }
     int NB = (D + 15) / 16;
     return ((size_t)(num_cu() + kStage2) * slab_len(NB) + (size_t)num_cu() * 4 * (NB * (NB + 1) / 2) * 256 + 1024) *
            sizeof(double);
@@ -954,6 +1016,35 @@ extern "C" int vt_glm_hessian(int family, const double* X, int64_t ldx, const do
     if (family < 0 || family > 2) return VT_ERR_BAD_ARG;
     if (!ws || ws_bytes < vt_glm_hessian_workspace_bytes(N, D)) return VT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (N > 0 && hess_split_ok(X, ldx, D)) {
+        const int D1 = VT_MID_D_MAX, t = D - D1, NB1 = D1 / 16;
+        const SplitWs lay = hess_split_ws(N, D);
+        char* base = (char*)ws;
+        double* off = (double*)(base + lay.off);
+        double* rr = r ? r : (double*)(base + lay.rtmp);
+        double* dd = d ? d : (double*)(base + lay.dtmp);
+        double* g2 = g ? g + D1 : (double*)(base + lay.g2);
+        void* rows_ws = base + lay.rows;
+        const size_t rows_bytes = vt_rows_workspace_bytes(t);
+        // the columns past 256 enter the linear predictor through the offset of the one-pass kernel
+        int rc = vt_gemv(X + D1, ldx, theta + D1, N, t, off, rows_ws, rows_bytes, stream);
+        if (rc != VT_OK) return rc;
+        if (offset) hipLaunchKernelGGL(k_add_vec, dim3(num_cu() * 4), dim3(256), 0, st, off, offset, N);
+        int nslabs = 0;
+        rc = vt_hess_mid(family, X, ldx, theta, y, w, off, scale, N, D1, rr, dd, (double*)(base + lay.slabs), &nslabs, st);
+        if (rc != VT_OK) return rc;
+        const int L1 = slab_len(NB1);
+        hipLaunchKernelGGL(k_hess_finalize, dim3((L1 + 15) / 16), dim3(256), 0, st, (const double*)(base + lay.slabs), L1,
+                           nslabs, NB1, D1, prior, theta, H, ldh, g);
+        // rows 256.. of H: X2^T diag(d) [X1 | X2]
+        rc = vt_gemm_tn(X + D1, ldx, t, X, ldx, D, dd, N, 1.0, nullptr, H + (int64_t)D1 * ldh, ldh, base + lay.tn,
+                        vt_gemm_tn_workspace_bytes(t, D), stream);
+        if (rc != VT_OK) return rc;
+        rc = vt_gemv_t2(X + D1, ldx, rr, w, N, t, g2, rows_ws, rows_bytes, stream);
+        if (rc != VT_OK) return rc;
+        hipLaunchKernelGGL(k_split_finish, dim3(64), dim3(256), 0, st, H, ldh, D1, D, prior, theta, g ? g : nullptr);
+        return vt_launch_status();
+    }
     if (N > 0 && vt_hess_mid_ok(X, ldx, D)) {
         // 129 <= D <= 256: one fused pass (vt_hess_mid.hip), slabs summed by the same finalize launch
         const int NBm = (D + 15) / 16;
