@@ -69,9 +69,9 @@ def test_sensitivity_large_d(N, D, family, relerr):
                                  (6001, 150), (4100, 160), (4200, 161), (4500, 176), (4800, 177), (5001, 192),
                                  (4097, 200), (4300, 208), (4444, 215), (4600, 224), (4700, 231), (4900, 240),
                                  (5100, 249), (8000, 255), (7777, 256),
-                                 # 256 < D <= 352: one-pass kernel on the first 256 columns + strip product (round 3)
+                                 # 256 < D <= 384: one-pass kernel on the first 256 columns + strip product (round 3)
                                  (1, 257), (23, 260), (4096, 257), (4111, 273), (5000, 300), (4099, 320), (4200, 337),
-                                 (4300, 352), (4100, 353)])
+                                 (4300, 352), (4100, 353), (4400, 369), (4500, 384), (4100, 385)])
 @pytest.mark.parametrize("family", ["logistic", "poisson", "gaussian"])
 def test_fused_hessian_grad_mid(N, D, family, relerr):
     from oracle import glm

@@ -940,13 +940,13 @@ static size_t large_ws_rows(int D) { return (vt_rows_workspace_bytes(D) + 255) /
 //   z = X1 theta1 + (X2 theta2 + offset)        -> k_glm_hess_mid on X1 with the bracket as its offset: H11, g1, r, d
 //   [H21 | H22] = X2^T diag(d) [X1 | X2]        -> vt_gemm_tn (the rectangular MFMA product, split over N)
 //   g2 = X2^T (w .* r)                          -> vt_gemm_t2's row kernel
-// 2.1 passes over X instead of the tiled route's ~3 panel reads; N = 2e6: D = 257 5.5 -> 4.1 ms, 320 6.1 -> 4.9,
-// 352 6.6 -> 5.8 (beyond, the strip's MFMA work catches up with the tiled route).  VT_HESS_NO_SPLIT=1: dev A/B switch.
+// 2.1 passes over X instead of the tiled route's ~3 panel reads; N = 2e6: D = 257 5.5 -> 4.1 ms, 320 6.1 -> 5.0,
+// 384 7.4 -> 6.7; past 384 the strip needs a second row of 128-column tiles and loses (D = 400: 12.9 against 9.2 ms).  VT_HESS_NO_SPLIT=1: dev A/B switch.
 extern "C" int vt_gemv(const double* X, int64_t ldx, const double* v, int64_t N, int D, double* out, void* ws,
                        size_t ws_bytes, void* stream);
 extern "C" int vt_gemv_t2(const double* X, int64_t ldx, const double* u1, const double* u2, int64_t N, int D,
                           double* out, void* ws, size_t ws_bytes, void* stream);
-constexpr int kSplitDMax = 352;
+constexpr int kSplitDMax = 384;
 
 __global__ __launch_bounds__(256) void k_add_vec(double* a, const double* b, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] += b[i];
