@@ -768,9 +768,22 @@ static bool wide_blocks() { return vt_mid_trsm_ok(kBW); }
 static size_t wide_pack_stride() {   // doubles per block pack: the larger of a chain pack and a small pack
     return (std::max(vt_mid_pack_bytes(kBW), (size_t)kPackStride * sizeof(double)) + 255) / 256 * 256 / sizeof(double);
 }
+// Diagonal blocks of the blocked solve: 384 columns while more than 448 are left; a rest of 385..448 columns is cut
+// as 256 + (129..192) -- a 384-column block would pay its two half-chains and two update passes for a few columns
+// (D = 385: 15.8 ms against 9.5 ms at D = 384) -- and a rest of <= 384 is one block (the whole chain in one launch).
+constexpr int kMaxWideBlocks = VT_DENSE_D_MAX / kBW + 3;
+static int wide_partition(int D, int* off) {   // off[0..n]: column offsets, returns n
+    int n = 0, o = 0;
+    off[0] = 0;
+    while (D - o > kBW + 64) { o += kBW; off[++n] = o; }
+    if (D - o > kBW) { o += VT_MID_D_MAX; off[++n] = o; }
+    off[++n] = D;
+    return n;
+}
 
 size_t vt_large_pack_bytes(int D) {
-    const int nblk = (D + kT - 1) / kT, nbw = (D + kBW - 1) / kBW;
+    int off[kMaxWideBlocks + 1];
+    const int nblk = (D + kT - 1) / kT, nbw = wide_partition(D, off);
     const size_t images = (size_t)2 * D * image_ld(D);
     return (images + std::max((size_t)nblk * kPackStride, (size_t)nbw * wide_pack_stride())) * sizeof(double);
 }
@@ -784,9 +797,10 @@ int vt_large_pack(const double* L, int ldl, int D, void* pack, hipStream_t st) {
     hipLaunchKernelGGL(k_copy_lower_and_transpose, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, L, ldl, D,
                        Lc, LT);
     if (wide_blocks()) {
-        const int nbw = (D + kBW - 1) / kBW;
+        int off[kMaxWideBlocks + 1];
+        const int nbw = wide_partition(D, off);
         for (int J = 0; J < nbw; ++J) {
-            const int o = J * kBW, Db = std::min(kBW, D - o);
+            const int o = off[J], Db = off[J + 1] - o;
             double* pk = packs + (size_t)J * wide_pack_stride();
             int rc = Db > VT_SMALL_D_MAX ? vt_mid_pack(Lc + (int64_t)o * Dl + o, Dl, Db, pk, st)
                                          : vt_potrf_pack_block(Lc + (int64_t)o * Dl + o, Dl, Db, nullptr, pk, 0, st);
@@ -809,12 +823,13 @@ static int large_trsm_rows_wide(const void* pack, int D, const double* B, int64_
     const double* Lc = (const double*)pack;
     const double* LT = Lc + (size_t)D * Dl;
     const double* packs = LT + (size_t)D * Dl;
-    const int nbw = (D + kBW - 1) / kBW;
+    int off[kMaxWideBlocks + 1];
+    const int nbw = wide_partition(D, off);
     int rc;
     // forward:  Y L^T = G with G = alpha * s .* B never materialised (block 0: the chain's row scale; later blocks:
     // the update's epilogue); the last block runs its forward AND backward chain in one launch
     for (int J = 0; J < nbw; ++J) {
-        const int o = J * kBW, Db = std::min(kBW, D - o);
+        const int o = off[J], Db = off[J + 1] - o;
         const double* pk = packs + (size_t)J * wide_pack_stride();
         const double* src = Out + o;
         int64_t lds_ = ldo;
@@ -827,17 +842,17 @@ static int large_trsm_rows_wide(const void* pack, int D, const double* B, int64_
                          rowscale, alpha);
             if (rc != VT_OK) return rc;
         }
-        if (J < nbw - 1) rc = vt_mid_trsm_rows_mode(pk, kBW, src, lds_, sc, al, N, Out + o, ldo, 1, st);
+        if (J < nbw - 1) rc = vt_mid_trsm_rows_mode(pk, Db, src, lds_, sc, al, N, Out + o, ldo, 1, st);
         else if (Db > VT_SMALL_D_MAX) rc = vt_mid_trsm_rows_mode(pk, Db, src, lds_, sc, al, N, Out + o, ldo, 0, st);
         else rc = vt_trsm_rows_mode(pk, Db, src, lds_, sc, al, N, Out + o, ldo, 0, st);
         if (rc != VT_OK) return rc;
     }
     for (int J = nbw - 2; J >= 0; --J) {   // backward:  Z L = Y
-        const int o = J * kBW, rest = D - o - kBW;
-        rc = gemm_nt(Out + o, ldo, N, kBW, Out + o + kBW, ldo, LT + (int64_t)o * Dl + o + kBW, Dl, rest, -1.0, 1.0,
+        const int o = off[J], Db = off[J + 1] - o, rest = D - o - Db;
+        rc = gemm_nt(Out + o, ldo, N, Db, Out + o + Db, ldo, LT + (int64_t)o * Dl + o + Db, Dl, rest, -1.0, 1.0,
                      false, st);
         if (rc != VT_OK) return rc;
-        rc = vt_mid_trsm_rows_mode(packs + (size_t)J * wide_pack_stride(), kBW, Out + o, ldo, nullptr, 1.0, N, Out + o,
+        rc = vt_mid_trsm_rows_mode(packs + (size_t)J * wide_pack_stride(), Db, Out + o, ldo, nullptr, 1.0, N, Out + o,
                                    ldo, 2, st);
         if (rc != VT_OK) return rc;
     }

@@ -19,7 +19,7 @@ int vt_mid_trsm_c(const void* pack, int D, const double* B, int64_t ldb, const d
 VT_MID_DECL(e) VT_MID_DECL(f) VT_MID_DECL(g) VT_MID_DECL(h) VT_MID_DECL(i) VT_MID_DECL(j)   // NB = 17-18, 19-20, 21, 22, 23, 24
 #undef VT_MID_DECL
 
-int vt_mid_trsm_d(const void* pack, const double* B, int64_t ldb, const double* rowscale, double alpha, int64_t N,
+int vt_mid_trsm_d(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha, int64_t N,
                   double* Out, int64_t ldo, int mode, hipStream_t st);
 
 namespace {
@@ -99,13 +99,13 @@ inline int mid_images(int D) {
 
 }  // namespace
 
-// mode 0: full solve (any 129 <= D <= 384); 1 / 2: forward-only / backward-only (D = VT_TRSM_ONEPASS_D_MAX only)
+// mode 0: full solve (any 129 <= D <= 384); 1 / 2: forward-only / backward-only (D = 384 or 256 only)
 int vt_mid_trsm_rows_mode(const void* pack, int D, const double* B, int64_t ldb, const double* rowscale, double alpha,
                           int64_t N, double* Out, int64_t ldo, int mode, hipStream_t st) {
     if (mode == 0) return vt_mid_trsm_rows(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, st);
-    if (D != VT_TRSM_ONEPASS_D_MAX) return VT_ERR_UNSUPPORTED;
+    if (D != VT_TRSM_ONEPASS_D_MAX && D != VT_MID_D_MAX) return VT_ERR_UNSUPPORTED;
     if (N == 0) return VT_OK;
-    return vt_mid_trsm_d(pack, B, ldb, rowscale, alpha, N, Out, ldo, mode, st);
+    return vt_mid_trsm_d(pack, D, B, ldb, rowscale, alpha, N, Out, ldo, mode, st);
 }
 
 // The one-pass chain holds a 16 x D tile of right-hand sides per wave: 8 D / 16 + ~60 registers of the 256 a wave has
