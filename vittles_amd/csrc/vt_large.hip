@@ -320,7 +320,12 @@ int gemm_nt(double* C, int64_t ldc, int64_t M, int N, const double* A, int64_t l
             hipLaunchKernelGGL((k_gemm_nt_lds<true>), grid, dim3(512), kGemmLdsBytes, st, a);
         } else {
             // persistent over the row tiles: two workgroups per CU and column block
-            const unsigned gx = (unsigned)std::min<int64_t>(grid.x, std::max(1, 2 * num_cu() / (int)grid.y));
+            // gx a multiple of 8: workgroup x + y gx runs on XCD (x + y gx) % 8, so the column tiles y of one row
+            // tile x share an XCD and with it the L2 lines of the A rows they all read (VT_GEMM_NT_GX_ANY=1: dev A/B;
+            // measured at D = 512 / 1000 / 2000: no change in wall time -- the product is not bound by that traffic)
+            static const bool gx_any = getenv("VT_GEMM_NT_GX_ANY") != nullptr;
+            unsigned gx = (unsigned)std::min<int64_t>(grid.x, std::max(1, 2 * num_cu() / (int)grid.y));
+            if (!gx_any && gx >= 8) gx &= ~7u;
             hipLaunchKernelGGL((k_gemm_nt_lds<false>), dim3(gx, grid.y), dim3(512), kGemmLdsBytes, st, a);
         }
         return vt_launch_status();
