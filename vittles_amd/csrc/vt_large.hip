@@ -780,7 +780,9 @@ constexpr int kMaxWideBlocks = VT_DENSE_D_MAX / kBW + 3;
 static int wide_partition(int D, int* off) {   // off[0..n]: column offsets, returns n
     int n = 0, o = 0;
     off[0] = 0;
-    while (D - o > kBW + 64) { o += kBW; off[++n] = o; }
+    static const int rest_env = getenv("VT_WIDE_REST") ? atoi(getenv("VT_WIDE_REST")) : 64;   // dev switch
+    const int rest = std::min(std::max(rest_env, 0), VT_MID_D_MAX);
+    while (D - o > kBW + rest) { o += kBW; off[++n] = o; }
     if (D - o > kBW) { o += VT_MID_D_MAX; off[++n] = o; }
     off[++n] = D;
     return n;
